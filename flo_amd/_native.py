@@ -1,0 +1,88 @@
+"""ctypes loader of the product library flo_amd/libflo_hip.so (C ABI in include/flo_hip.h).
+
+There is no CPU path behind this module: if the shared library is missing, or no gfx950 device can be opened,
+every entry point raises. torch is imported first on purpose — its bundled HIP runtime carries the same SONAME
+as /opt/rocm's, so loading in this order gives the process ONE HIP runtime and lets torch tensors / RCCL and
+this library's kernels share device pointers and streams.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libflo_hip.so")
+_LIB = None
+
+OK = 0
+MODE_LOSSLESS, MODE_LOSSY = 0, 1
+
+EXPORTS = [
+    "flo_ctx_create", "flo_ctx_destroy", "flo_last_error", "flo_last_create_error", "flo_free", "flo_ctx_device_info",
+    "flo_encode_lossy", "flo_encode_lossless", "flo_encode_batch",
+    "flo_batch_create", "flo_batch_destroy", "flo_batch_clip_device_ptr", "flo_batch_upload",
+    "flo_batch_fill_synthetic", "flo_batch_encode", "flo_batch_sync", "flo_batch_data_bytes", "flo_batch_fetch",
+    "flo_batch_device_streams",
+    "flo_ctx_profile_enable", "flo_ctx_profile_query", "flo_ctx_profile_reset", "flo_ctx_force_path", "flo_ctx_stream",
+    "flo_mdct_forward", "flo_lossy_analyze", "flo_lossy_quantize", "flo_sparse_pack",
+]
+
+
+class FloError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _SO
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_SO):
+        raise FloError(f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). flo_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (one HIP runtime per process, see module docstring)
+    except Exception:
+        pass
+    L = C.CDLL(_SO)
+    vp, sz, u8p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint8)
+    L.flo_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.flo_ctx_destroy.argtypes = [vp]
+    L.flo_ctx_destroy.restype = None
+    L.flo_last_error.argtypes = [vp]
+    L.flo_last_error.restype = C.c_char_p
+    L.flo_last_create_error.restype = C.c_char_p
+    L.flo_free.argtypes = [vp]
+    L.flo_free.restype = None
+    L.flo_ctx_device_info.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+    L.flo_encode_lossy.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_float, C.c_char_p, sz, C.POINTER(vp), C.POINTER(sz)]
+    L.flo_encode_lossless.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_char_p, sz,
+                                      C.POINTER(vp), C.POINTER(sz)]
+    L.flo_encode_batch.argtypes = [vp, C.c_int, sz, C.POINTER(vp), C.POINTER(sz), C.c_uint32, C.c_uint8, C.c_float,
+                                   C.POINTER(vp), C.POINTER(sz)]
+    L.flo_batch_create.argtypes = [vp, C.c_int, sz, C.POINTER(sz), C.c_uint32, C.c_uint8, C.c_float, C.POINTER(vp)]
+    L.flo_batch_destroy.argtypes = [vp]
+    L.flo_batch_destroy.restype = None
+    L.flo_batch_clip_device_ptr.argtypes = [vp, sz]
+    L.flo_batch_clip_device_ptr.restype = vp
+    L.flo_batch_upload.argtypes = [vp, sz, vp]
+    L.flo_batch_fill_synthetic.argtypes = [vp, C.c_uint32, C.c_uint64]
+    L.flo_batch_encode.argtypes = [vp, C.c_int]
+    L.flo_batch_sync.argtypes = [vp]
+    L.flo_batch_data_bytes.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.flo_batch_fetch.argtypes = [vp, sz, C.c_char_p, sz, C.POINTER(vp), C.POINTER(sz)]
+    L.flo_batch_device_streams.argtypes = [vp, C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint64)),
+                                           C.POINTER(C.POINTER(C.c_uint64))]
+    L.flo_ctx_profile_enable.argtypes = [vp, C.c_int]
+    L.flo_ctx_profile_query.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.flo_ctx_profile_reset.argtypes = [vp]
+    L.flo_ctx_force_path.argtypes = [vp, C.c_int]
+    L.flo_ctx_stream.argtypes = [vp]
+    L.flo_ctx_stream.restype = vp
+    L.flo_mdct_forward.argtypes = [vp, vp, sz, vp]
+    L.flo_lossy_analyze.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_float, vp, vp, vp, C.POINTER(sz)]
+    L.flo_lossy_quantize.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_float, vp, vp]
+    L.flo_sparse_pack.argtypes = [vp, vp, sz, vp, sz, vp]
+    _LIB = L
+    return L

@@ -1,0 +1,309 @@
+"""Host-side mirror of libflo's encoder interface, bound to the HIP library through its C ABI.
+
+Same names, argument meaning and error behaviour as the reference (all paths under /root/reference):
+  Encoder(sample_rate, channels, bit_depth).with_compression(level).encode(samples, metadata)
+        -> libflo/src/lossless/encoder.rs:17-45
+  LossyEncoder / TransformEncoder(sample_rate, channels, quality).encode_to_flo(samples, metadata)
+        -> libflo/src/lossy/encoder.rs:36-53,167-239 (re-export lib.rs:21-24)
+  QualityPreset                      -> libflo/src/lossy/mod.rs:19-128
+  encode / encode_lossy / encode_with_bitrate (free functions, metadata passed through verbatim)
+        -> libflo/src/lib.rs:97-206  (the reference adds analysis metadata first; that is out of scope)
+Errors surface as FloError(message), the analogue of FloResult<T> = Result<T, String> (core/types.rs:281).
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _native
+from ._native import FloError, MODE_LOSSLESS, MODE_LOSSY
+
+
+class QualityPreset(enum.IntEnum):
+    """lossy/mod.rs:19-128"""
+    Low = 0
+    Medium = 1
+    High = 2
+    VeryHigh = 3
+    Transparent = 4
+
+    def as_f32(self) -> float:
+        return [0.0, 0.35, 0.55, 0.75, 1.0][int(self)]
+
+    @staticmethod
+    def from_f32(q: float) -> "QualityPreset":
+        if q < 0.2:
+            return QualityPreset.Low
+        if q < 0.45:
+            return QualityPreset.Medium
+        if q < 0.65:
+            return QualityPreset.High
+        if q < 0.85:
+            return QualityPreset.VeryHigh
+        return QualityPreset.Transparent
+
+    @staticmethod
+    def from_bitrate(bitrate_kbps: int, sample_rate: int, channels: int) -> "QualityPreset":
+        raw_kbps = (sample_rate * channels * 16) // 1000
+        ratio = np.float32(raw_kbps) / np.float32(bitrate_kbps)
+        if ratio > 20.0:
+            return QualityPreset.Low
+        if ratio > 10.0:
+            return QualityPreset.Medium
+        if ratio > 6.0:
+            return QualityPreset.High
+        if ratio > 4.0:
+            return QualityPreset.VeryHigh
+        return QualityPreset.Transparent
+
+    def expected_ratio(self) -> float:
+        return [30.0, 10.0, 6.0, 4.0, 3.0][int(self)]
+
+    def equivalent_bitrate(self) -> int:
+        return [48, 128, 192, 256, 320][int(self)]
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+
+
+class Context:
+    """One per host thread / GPU (flo_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._L = _native.lib()
+        h = C.c_void_p()
+        rc = self._L.flo_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise FloError(self._L.flo_last_create_error().decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.flo_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise FloError(self._L.flo_last_error(self._h).decode())
+
+    def _take(self, ptr, n):
+        data = C.string_at(ptr.value, n.value) if ptr.value else b""
+        self._L.flo_free(ptr)
+        return data
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, hbm = C.c_int(), C.c_uint64()
+        self._chk(self._L.flo_ctx_device_info(self._h, name, 256, C.byref(cus), C.byref(hbm)))
+        return name.value.decode(), cus.value, hbm.value
+
+    def force_path(self, which: int):
+        self._chk(self._L.flo_ctx_force_path(self._h, which))
+
+    # -- one clip ---------------------------------------------------------------------------------------
+    def encode_lossy(self, samples, sample_rate, channels, quality, metadata=b"") -> bytes:
+        p = _f32(samples)
+        out, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.flo_encode_lossy(self._h, p.ctypes.data, p.size, sample_rate, channels, quality,
+                                           metadata, len(metadata), C.byref(out), C.byref(n)))
+        return self._take(out, n)
+
+    def encode_lossless(self, samples, sample_rate, channels, bit_depth=16, level=5, metadata=b"") -> bytes:
+        p = _f32(samples)
+        out, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.flo_encode_lossless(self._h, p.ctypes.data, p.size, sample_rate, channels, bit_depth, level,
+                                              metadata, len(metadata), C.byref(out), C.byref(n)))
+        return self._take(out, n)
+
+    def encode_batch(self, mode, clips, sample_rate, channels, quality_or_level):
+        arrs = [_f32(c) for c in clips]
+        k = len(arrs)
+        ptrs = (C.c_void_p * k)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * k)(*[a.size for a in arrs])
+        outs, olens = (C.c_void_p * k)(), (C.c_size_t * k)()
+        self._chk(self._L.flo_encode_batch(self._h, mode, k, ptrs, lens, sample_rate, channels, quality_or_level, outs, olens))
+        res = []
+        for i in range(k):
+            res.append(C.string_at(outs[i], olens[i]) if outs[i] else b"")
+            self._L.flo_free(outs[i])
+        return res
+
+    # -- stage-level entry points (parity tests) -----------------------------------------------------------
+    def mdct_forward(self, frames):
+        f = _f32(frames)
+        n = f.size // 2048
+        out = np.zeros(n * 1024, np.float32)
+        self._chk(self._L.flo_mdct_forward(self._h, f.ctypes.data, n, out.ctypes.data))
+        return out.reshape(n, 1024)
+
+    def lossy_analyze(self, samples, sample_rate, channels, quality):
+        p = _f32(samples)
+        hops = ((p.size // channels) + 1024 + 1023) // 1024
+        coeffs = np.zeros((hops, channels, 1024), np.float32)
+        q = np.zeros((hops, channels, 1024), np.int16)
+        sfw = np.zeros((hops, channels, 25), np.uint16)
+        nh = C.c_size_t()
+        self._chk(self._L.flo_lossy_analyze(self._h, p.ctypes.data, p.size, sample_rate, channels, quality,
+                                            coeffs.ctypes.data, q.ctypes.data, sfw.ctypes.data, C.byref(nh)))
+        assert nh.value == hops
+        return dict(coeffs=coeffs, q=q, sf_words=sfw)
+
+    def lossy_quantize(self, coeffs, sample_rate, quality):
+        c = np.ascontiguousarray(coeffs, np.float32)
+        hops, channels = c.shape[0], c.shape[1]
+        q = np.zeros((hops, channels, 1024), np.int16)
+        sfw = np.zeros((hops, channels, 25), np.uint16)
+        self._chk(self._L.flo_lossy_quantize(self._h, c.ctypes.data, hops, sample_rate, channels, quality,
+                                             q.ctypes.data, sfw.ctypes.data))
+        return dict(q=q, sf_words=sfw)
+
+    def sparse_pack(self, q):
+        q = np.ascontiguousarray(q, np.int16).reshape(-1, 1024)
+        n = q.shape[0]
+        out = np.zeros(n * 2080, np.uint8)
+        off = np.zeros(n + 1, np.uint32)
+        self._chk(self._L.flo_sparse_pack(self._h, q.ctypes.data, n, out.ctypes.data, out.size, off.ctypes.data))
+        return [out[off[i]:off[i + 1]].tobytes() for i in range(n)]
+
+    # -- profiling hooks --------------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self._L.flo_ctx_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self._L.flo_ctx_profile_reset(self._h))
+
+    def profile_query(self, kernel: str):
+        ms, n = C.c_double(), C.c_uint64()
+        self._chk(self._L.flo_ctx_profile_query(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def stream(self):
+        return self._L.flo_ctx_stream(self._h)
+
+
+class Batch:
+    """Device-resident batch of clips (flo_batch): PCM stays in HBM, bitstreams are left in HBM."""
+
+    def __init__(self, ctx: Context, mode, n_interleaved, sample_rate, channels, quality_or_level):
+        self.ctx, self._L = ctx, ctx._L
+        self.n_clips = len(n_interleaved)
+        self.n_interleaved = list(int(x) for x in n_interleaved)
+        lens = (C.c_size_t * self.n_clips)(*self.n_interleaved)
+        h = C.c_void_p()
+        ctx._chk(self._L.flo_batch_create(ctx._h, mode, self.n_clips, lens, sample_rate, channels, quality_or_level, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.flo_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clip_device_ptr(self, clip):
+        return self._L.flo_batch_clip_device_ptr(self._h, clip)
+
+    def upload(self, clip, samples):
+        p = _f32(samples)
+        assert p.size == self.n_interleaved[clip]
+        self.ctx._chk(self._L.flo_batch_upload(self._h, clip, p.ctypes.data))
+        self.ctx._chk(self._L.flo_batch_sync(self._h))   # p may be released by the caller
+
+    def fill_synthetic(self, seed=0xF10A0D10, clip_id0=0):
+        self.ctx._chk(self._L.flo_batch_fill_synthetic(self._h, seed, clip_id0))
+
+    def encode(self, which=0):
+        self.ctx._chk(self._L.flo_batch_encode(self._h, which))
+
+    def sync(self):
+        self.ctx._chk(self._L.flo_batch_sync(self._h))
+
+    def data_bytes(self):
+        t = C.c_uint64()
+        self.ctx._chk(self._L.flo_batch_data_bytes(self._h, C.byref(t)))
+        return t.value
+
+    def fetch(self, clip, metadata=b"") -> bytes:
+        out, n = C.c_void_p(), C.c_size_t()
+        self.ctx._chk(self._L.flo_batch_fetch(self._h, clip, metadata, len(metadata), C.byref(out), C.byref(n)))
+        return self.ctx._take(out, n)
+
+    def device_streams(self):
+        base = C.c_void_p()
+        offs, sizes = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        self.ctx._chk(self._L.flo_batch_device_streams(self._h, C.byref(base), C.byref(offs), C.byref(sizes)))
+        return base.value, [offs[i] for i in range(self.n_clips)], [sizes[i] for i in range(self.n_clips)]
+
+
+_default_ctx = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+class Encoder:
+    """lossless::Encoder — lossless/encoder.rs:9-45"""
+
+    def __init__(self, sample_rate: int, channels: int, bit_depth: int, ctx: Context = None):
+        self.sample_rate, self.channels, self.bit_depth = sample_rate, channels, bit_depth
+        self.compression_level = 5
+        self._ctx = ctx
+
+    def with_compression(self, level: int) -> "Encoder":
+        self.compression_level = min(int(level), 9)
+        return self
+
+    def encode(self, samples, metadata: bytes = b"") -> bytes:
+        ctx = self._ctx or default_context()
+        return ctx.encode_lossless(samples, self.sample_rate, self.channels, self.bit_depth, self.compression_level, metadata)
+
+
+class TransformEncoder:
+    """lossy::TransformEncoder — lossy/encoder.rs:6-53,167-239. One fresh encoder per clip is the contract."""
+
+    def __init__(self, sample_rate: int, channels: int, quality: float, ctx: Context = None):
+        self.sample_rate, self.channels = sample_rate, channels
+        self.quality = float(min(max(quality, 0.0), 1.0))
+        self._ctx = ctx
+
+    def set_quality(self, quality: float):
+        self.quality = float(min(max(quality, 0.0), 1.0))
+
+    def encode_to_flo(self, samples, metadata: bytes = b"") -> bytes:
+        ctx = self._ctx or default_context()
+        return ctx.encode_lossy(samples, self.sample_rate, self.channels, self.quality, metadata)
+
+
+LossyEncoder = TransformEncoder
+
+
+def encode(samples, sample_rate, channels, bit_depth, metadata=None) -> bytes:
+    """lib.rs:97-117 (without the analysis-metadata step: metadata is passed through verbatim)"""
+    return Encoder(sample_rate, channels, bit_depth).encode(samples, metadata or b"")
+
+
+def encode_lossy(samples, sample_rate, channels, _bit_depth, quality: int, metadata=None) -> bytes:
+    """lib.rs:135-166: quality level 0-4 -> 0.0/0.35/0.55/0.75/1.0"""
+    q = {0: 0.0, 1: 0.35, 2: 0.55, 3: 0.75}.get(int(quality), 1.0)
+    return TransformEncoder(sample_rate, channels, q).encode_to_flo(samples, metadata or b"")
+
+
+def encode_with_bitrate(samples, sample_rate, channels, _bit_depth, target_bitrate_kbps, metadata=None) -> bytes:
+    """lib.rs:181-206"""
+    q = QualityPreset.from_bitrate(target_bitrate_kbps, sample_rate, channels).as_f32()
+    return TransformEncoder(sample_rate, channels, q).encode_to_flo(samples, metadata or b"")

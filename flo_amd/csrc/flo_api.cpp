@@ -1,0 +1,709 @@
+// flo_api.cpp — C ABI of libflo_hip.so (see include/flo_hip.h): context, device-resident batches, .flo assembly.
+// Host code only; the kernels live in lossy_kernels.hip / lossless_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/flo_hip.h"
+#include "container.hpp"
+#include "lossless_kernels.hpp"
+#include "lossy_kernels.hpp"
+#include "tables.hpp"
+
+using namespace flo;
+
+// ------------------------------------------------------------------------------------------------ context
+struct TableSet {
+    LossyTablesHost host;
+    void *blob = nullptr;  // one device allocation holding every table
+    LossyDevTables dev{};
+};
+
+struct ProfRec {
+    std::string name;
+    hipEvent_t a, b;
+};
+
+struct flo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<TableSet *> tables;
+    bool profile = false;
+    std::vector<ProfRec> prof;
+    int force_path = 0;
+    hipDeviceProp_t prop{};
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(flo_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+#define HIPCHK(ctx, expr)                                                                               \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(ctx, FLO_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+extern "C" const char *flo_last_create_error(void) { return g_create_err.c_str(); }
+extern "C" const char *flo_last_error(const flo_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" void flo_free(void *p) { free(p); }
+
+extern "C" int flo_ctx_create(int device, flo_ctx **out) {
+    if (!out) return FLO_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        g_create_err = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+                       " (libflo_hip has no CPU fallback)";
+        return FLO_ERR_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        g_create_err = "device index out of range";
+        return FLO_ERR_ARG;
+    }
+    flo_ctx *c = new flo_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&c->prop, device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_err = std::string("device init failed: ") + hipGetErrorString(e);
+        delete c;
+        return FLO_ERR_DEVICE;
+    }
+    if (std::string(c->prop.gcnArchName).find("gfx950") == std::string::npos) {
+        g_create_err = std::string("device is ") + c->prop.gcnArchName + ", this library carries gfx950 code only";
+        hipStreamDestroy(c->stream);
+        delete c;
+        return FLO_ERR_DEVICE;
+    }
+    *out = c;
+    return FLO_OK;
+}
+
+extern "C" void flo_ctx_destroy(flo_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto *t : c->tables) {
+        if (t->blob) hipFree(t->blob);
+        delete t;
+    }
+    for (auto &r : c->prof) {
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int flo_ctx_device_info(const flo_ctx *c, char *name, size_t cap, int *cus, uint64_t *hbm) {
+    if (!c) return FLO_ERR_ARG;
+    if (name && cap) snprintf(name, cap, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    if (cus) *cus = c->prop.multiProcessorCount;
+    if (hbm) *hbm = (uint64_t)c->prop.totalGlobalMem;
+    return FLO_OK;
+}
+extern "C" void *flo_ctx_stream(flo_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int flo_ctx_force_path(flo_ctx *c, int which) {
+    if (!c || which < 0 || which > 2) return FLO_ERR_ARG;
+    c->force_path = which;
+    return FLO_OK;
+}
+
+// ---- profiling hooks -----------------------------------------------------------------------------------
+extern "C" int flo_ctx_profile_enable(flo_ctx *c, int on) {
+    if (!c) return FLO_ERR_ARG;
+    c->profile = on != 0;
+    return FLO_OK;
+}
+extern "C" int flo_ctx_profile_reset(flo_ctx *c) {
+    if (!c) return FLO_ERR_ARG;
+    for (auto &r : c->prof) {
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    c->prof.clear();
+    return FLO_OK;
+}
+extern "C" int flo_ctx_profile_query(flo_ctx *c, const char *kernel, double *total_ms, uint64_t *launches) {
+    if (!c || !kernel) return FLO_ERR_ARG;
+    double tot = 0;
+    uint64_t n = 0;
+    for (auto &r : c->prof) {
+        if (r.name != kernel) continue;
+        float ms = 0;
+        HIPCHK(c, hipEventSynchronize(r.b));
+        HIPCHK(c, hipEventElapsedTime(&ms, r.a, r.b));
+        tot += ms;
+        n++;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return FLO_OK;
+}
+
+template <typename F>
+static int timed_launch(flo_ctx *c, const char *name, F &&launch) {
+    if (!c->profile) {
+        int rc = launch();
+        return rc == 0 ? FLO_OK : fail(c, FLO_ERR_DEVICE, std::string("launch ") + name + " failed: " +
+                                                              hipGetErrorString((hipError_t)(rc > 0 ? rc : 1)));
+    }
+    ProfRec r;
+    r.name = name;
+    HIPCHK(c, hipEventCreate(&r.a));
+    HIPCHK(c, hipEventCreate(&r.b));
+    HIPCHK(c, hipEventRecord(r.a, c->stream));
+    int rc = launch();
+    HIPCHK(c, hipEventRecord(r.b, c->stream));
+    c->prof.push_back(r);
+    return rc == 0 ? FLO_OK : fail(c, FLO_ERR_DEVICE, std::string("launch ") + name + " failed");
+}
+
+// ---- constant tables -----------------------------------------------------------------------------------
+static int get_tables(flo_ctx *c, uint32_t sr, float quality, TableSet **out) {
+    float q = quality < 0.f ? 0.f : (quality > 1.f ? 1.f : quality);
+    if (quality != quality) q = 0.f;  // NaN clamps to NaN in Rust; the threshold formula then yields NaN -> treat as 0
+    for (auto *t : c->tables)
+        if (t->host.sample_rate == sr && t->host.quality == q) {
+            *out = t;
+            return FLO_OK;
+        }
+    TableSet *t = new TableSet();
+    build_lossy_tables(sr, q, t->host);
+    const LossyTablesHost &h = t->host;
+    struct Part {
+        const void *src;
+        size_t bytes;
+        size_t off;
+    };
+    std::vector<Part> parts;
+    size_t total = 0;
+    auto add = [&](const void *p, size_t b) {
+        total = (total + 255) & ~(size_t)255;
+        parts.push_back({p, b, total});
+        total += b;
+        return parts.size() - 1;
+    };
+    size_t i_pack = add(h.pack.data(), h.pack.size() * 4), i_athdb = add(h.ath_db.data(), h.ath_db.size() * 4),
+           i_band = add(h.band.data(), h.band.size()), i_bc = add(h.band_count.data(), h.band_count.size() * 4),
+           i_s10 = add(h.s10d.data(), h.s10d.size() * 4), i_lb = add(h.lane_bnd.data(), h.lane_bnd.size() * 4),
+           i_ls = add(h.lane_slot0.data(), h.lane_slot0.size() * 4), i_bs = add(h.band_slot0.data(), h.band_slot0.size() * 4);
+    hipError_t e = hipMalloc(&t->blob, total);
+    if (e != hipSuccess) {
+        delete t;
+        return fail(c, FLO_ERR_NOMEM, std::string("hipMalloc tables: ") + hipGetErrorString(e));
+    }
+    std::vector<uint8_t> stage(total, 0);
+    for (auto &p : parts) memcpy(stage.data() + p.off, p.src, p.bytes);
+    e = hipMemcpy(t->blob, stage.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(t->blob);
+        delete t;
+        return fail(c, FLO_ERR_DEVICE, std::string("hipMemcpy tables: ") + hipGetErrorString(e));
+    }
+    auto P = [&](size_t i) { return (const char *)t->blob + parts[i].off; };
+    t->dev.pack = (const float4 *)P(i_pack);
+    t->dev.ath_db = (const float *)P(i_athdb);
+    t->dev.band = (const uint8_t *)P(i_band);
+    t->dev.band_count = (const float *)P(i_bc);
+    t->dev.s10d = (const float *)P(i_s10);
+    t->dev.lane_bnd = (const uint32_t *)P(i_lb);
+    t->dev.lane_slot0 = (const uint32_t *)P(i_ls);
+    t->dev.band_slot0 = (const uint32_t *)P(i_bs);
+    t->dev.max_band_slots = h.max_band_slots;
+    t->dev.smr_thr = h.smr_threshold;
+    t->dev.q_transparent = h.q_transparent;
+    if (h.n_slots > kSlotCap) {
+        hipFree(t->blob);
+        delete t;
+        return fail(c, FLO_ERR_ARG, "band segment table exceeds capacity");
+    }
+    c->tables.push_back(t);
+    *out = t;
+    return FLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ batch
+struct flo_batch {
+    flo_ctx *ctx = nullptr;
+    int mode = 0;
+    size_t n_clips = 0;
+    uint32_t sr = 0;
+    uint8_t ch = 0;
+    float qol = 0;
+    uint8_t bit_depth = 16;
+    TableSet *ts = nullptr;
+    // plan (host)
+    std::vector<uint64_t> n_il, clip_off, clip_nsf, clip_frame0, out_off, out_cap;
+    std::vector<uint32_t> hops;
+    uint64_t total_frames = 0, total_floats = 0, out_bytes = 0;
+    // device
+    float *d_pcm = nullptr;
+    uint64_t *d_plan = nullptr;  // clip_off | clip_nsf | clip_frame0 | out_off
+    uint32_t *d_hops = nullptr;
+    uint8_t *d_out = nullptr;
+    uint32_t *d_frame_size = nullptr;
+    uint64_t *d_clip_bytes = nullptr;
+    float *d_at = nullptr, *d_sprev = nullptr;
+    uint8_t *d_slots = nullptr;
+    uint64_t *d_frame_off = nullptr;
+    // analysis buffers (optional)
+    float *d_dbg_coeffs = nullptr;
+    short *d_dbg_q = nullptr;
+    unsigned short *d_dbg_sfw = nullptr;
+    const float *d_in_coeffs = nullptr;
+    // results (host, valid after sync)
+    bool encoded = false, synced = false;
+    std::vector<uint64_t> h_clip_bytes;
+    std::vector<uint32_t> h_frame_size;
+    // lossless
+    LosslessPlan *ll = nullptr;
+};
+
+static size_t lossy_max_frame_bytes(int ch) { return 12 + 50 * (size_t)ch + (size_t)ch * (4 + 2064); }
+
+extern "C" void flo_batch_destroy(flo_batch *b) {
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    void *ptrs[] = {b->d_pcm, b->d_plan, b->d_hops, b->d_out, b->d_frame_size, b->d_clip_bytes, b->d_at,
+                    b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    if (b->ll) lossless_plan_destroy(b->ll);
+    delete b;
+}
+
+extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size_t *n_interleaved, uint32_t sr,
+                                uint8_t ch, float qol, flo_batch **out) {
+    if (!c || !out || (n_clips && !n_interleaved)) return FLO_ERR_ARG;
+    *out = nullptr;
+    if (ch == 0 || sr == 0) return fail(c, FLO_ERR_ARG, "sample_rate and channels must be non-zero");
+    if (mode != FLO_MODE_LOSSY && mode != FLO_MODE_LOSSLESS) return fail(c, FLO_ERR_ARG, "unknown mode");
+    if (mode == FLO_MODE_LOSSY && ch > 2)
+        return fail(c, FLO_ERR_ARG, "lossy encode on device supports 1 or 2 channels in this build");
+    HIPCHK(c, hipSetDevice(c->device));
+    flo_batch *b = new flo_batch();
+    b->ctx = c;
+    b->mode = mode;
+    b->n_clips = n_clips;
+    b->sr = sr;
+    b->ch = ch;
+    b->qol = qol;
+    b->n_il.assign(n_interleaved, n_interleaved + n_clips);
+    b->clip_off.resize(n_clips);
+    b->clip_nsf.resize(n_clips);
+    uint64_t off = 0;
+    for (size_t i = 0; i < n_clips; i++) {
+        b->clip_off[i] = off;
+        b->clip_nsf[i] = n_interleaved[i] / ch;  // trailing partial sample-frame is dropped (encoder.rs:174)
+        off += (n_interleaved[i] + 3) & ~(uint64_t)3;
+    }
+    b->total_floats = off;
+    int rc = FLO_OK;
+    auto bail = [&](int code) {
+        flo_batch_destroy(b);
+        return code;
+    };
+#define BCHK(expr)                                                                                  \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            fail(c, e_ == hipErrorOutOfMemory ? FLO_ERR_NOMEM : FLO_ERR_DEVICE,                     \
+                 std::string(#expr) + ": " + hipGetErrorString(e_));                                \
+            return bail(e_ == hipErrorOutOfMemory ? FLO_ERR_NOMEM : FLO_ERR_DEVICE);                \
+        }                                                                                           \
+    } while (0)
+    BCHK(hipMalloc(&b->d_pcm, (b->total_floats + 4) * sizeof(float)));
+    if (mode == FLO_MODE_LOSSY) {
+        rc = get_tables(c, sr, qol, &b->ts);
+        if (rc != FLO_OK) return bail(rc);
+        b->hops.resize(n_clips);
+        b->clip_frame0.resize(n_clips);
+        b->out_off.resize(n_clips);
+        b->out_cap.resize(n_clips);
+        uint64_t f = 0, o = 0;
+        const size_t mfb = lossy_max_frame_bytes(ch);
+        for (size_t i = 0; i < n_clips; i++) {
+            uint64_t h = (b->clip_nsf[i] + 1024 + 1023) / 1024;  // encoder.rs:177-179
+            b->hops[i] = (uint32_t)h;
+            b->clip_frame0[i] = f;
+            f += h;
+            b->out_off[i] = o;
+            b->out_cap[i] = ((h * mfb + 64) + 15) & ~(uint64_t)15;
+            o += b->out_cap[i];
+        }
+        b->total_frames = f;
+        b->out_bytes = o;
+        std::vector<uint64_t> plan(4 * n_clips);
+        for (size_t i = 0; i < n_clips; i++) {
+            plan[i] = b->clip_off[i];
+            plan[n_clips + i] = b->clip_nsf[i];
+            plan[2 * n_clips + i] = b->clip_frame0[i];
+            plan[3 * n_clips + i] = b->out_off[i];
+        }
+        BCHK(hipMalloc(&b->d_plan, (plan.size() + 1) * 8));
+        BCHK(hipMalloc(&b->d_hops, (n_clips + 1) * 4));
+        BCHK(hipMalloc(&b->d_out, b->out_bytes + 64));
+        BCHK(hipMalloc(&b->d_frame_size, (b->total_frames + 1) * 4));
+        BCHK(hipMalloc(&b->d_clip_bytes, (n_clips + 1) * 8));
+        if (n_clips) {
+            BCHK(hipMemcpy(b->d_plan, plan.data(), plan.size() * 8, hipMemcpyHostToDevice));
+            BCHK(hipMemcpy(b->d_hops, b->hops.data(), n_clips * 4, hipMemcpyHostToDevice));
+        }
+    } else {
+        uint8_t level = qol < 0 ? 0 : (qol > 9 ? 9 : (uint8_t)qol);  // with_compression: level.min(9)
+        b->qol = level;
+        std::string err;
+        b->ll = lossless_plan_create(b->n_il, b->clip_off, sr, ch, level, b->d_pcm, err);
+        if (!b->ll) {
+            fail(c, FLO_ERR_NOMEM, "lossless plan: " + err);
+            return bail(FLO_ERR_NOMEM);
+        }
+    }
+#undef BCHK
+    *out = b;
+    return FLO_OK;
+}
+
+extern "C" float *flo_batch_clip_device_ptr(flo_batch *b, size_t clip) {
+    if (!b || clip >= b->n_clips) return nullptr;
+    return b->d_pcm + b->clip_off[clip];
+}
+
+extern "C" int flo_batch_upload(flo_batch *b, size_t clip, const float *pcm) {
+    if (!b || clip >= b->n_clips || (!pcm && b->n_il[clip])) return FLO_ERR_ARG;
+    flo_ctx *c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->n_il[clip])
+        HIPCHK(c, hipMemcpyAsync(b->d_pcm + b->clip_off[clip], pcm, b->n_il[clip] * sizeof(float),
+                                 hipMemcpyHostToDevice, c->stream));
+    b->encoded = b->synced = false;
+    return FLO_OK;
+}
+
+extern "C" int flo_batch_fill_synthetic(flo_batch *b, uint32_t seed, uint64_t clip_id0) {
+    if (!b) return FLO_ERR_ARG;
+    flo_ctx *c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!b->n_clips) return FLO_OK;
+    // plan arrays needed on device: clip_off, clip_nsf
+    uint64_t *d_off = nullptr;
+    std::vector<uint64_t> tmp(2 * b->n_clips);
+    for (size_t i = 0; i < b->n_clips; i++) {
+        tmp[i] = b->clip_off[i];
+        tmp[b->n_clips + i] = b->clip_nsf[i];
+    }
+    HIPCHK(c, hipMalloc(&d_off, tmp.size() * 8));
+    hipError_t e = hipMemcpyAsync(d_off, tmp.data(), tmp.size() * 8, hipMemcpyHostToDevice, c->stream);
+    int rc = 0;
+    if (e == hipSuccess)
+        rc = launch_synth_fill(b->d_pcm, (const unsigned long long *)d_off, (const unsigned long long *)d_off + b->n_clips, (int)b->n_clips, b->ch, seed, clip_id0, c->stream);
+    hipStreamSynchronize(c->stream);
+    hipFree(d_off);
+    if (e != hipSuccess || rc != 0) return fail(c, FLO_ERR_DEVICE, "synthetic fill failed");
+    b->encoded = b->synced = false;
+    return FLO_OK;
+}
+
+static LossyArgs make_args(flo_batch *b) {
+    LossyArgs A{};
+    A.T = b->ts->dev;
+    A.pcm = b->d_pcm;
+    const unsigned long long *plan = (const unsigned long long *)b->d_plan;
+    A.clip_off = plan;
+    A.clip_nsf = plan + b->n_clips;
+    A.clip_frame0 = plan + 2 * b->n_clips;
+    A.out_off = plan + 3 * b->n_clips;
+    A.clip_hops = b->d_hops;
+    A.nch = b->ch;
+    A.n_clips = (int)b->n_clips;
+    A.total_frames = b->total_frames;
+    A.out = b->d_out;
+    A.frame_size = b->d_frame_size;
+    A.clip_bytes = (unsigned long long *)b->d_clip_bytes;
+    A.a_t = b->d_at;
+    A.s_prev_out = b->d_sprev;
+    A.s_prev = b->d_sprev;
+    A.slots = b->d_slots;
+    A.frame_off = (unsigned long long *)b->d_frame_off;
+    A.dbg_coeffs = b->d_dbg_coeffs;
+    A.dbg_q = b->d_dbg_q;
+    A.dbg_sfw = b->d_dbg_sfw;
+    A.in_coeffs = b->d_in_coeffs;
+    return A;
+}
+
+extern "C" int flo_batch_encode(flo_batch *b, int which) {
+    if (!b) return FLO_ERR_ARG;
+    flo_ctx *c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    b->encoded = true;
+    b->synced = false;
+    if (!b->n_clips) return FLO_OK;
+    if (b->mode == FLO_MODE_LOSSLESS) {
+        std::string err;
+        int rc = lossless_encode_launch(b->ll, c->stream, c->profile ? 1 : 0, err);
+        return rc == 0 ? FLO_OK : fail(c, FLO_ERR_DEVICE, "lossless encode: " + err);
+    }
+    if (!b->total_frames) return FLO_OK;
+    if (which == 0) which = c->force_path;
+    if (which == 0) which = (b->n_clips * b->ch >= 512) ? 1 : 2;
+    if (which == 1) {
+        LossyArgs A = make_args(b);
+        return timed_launch(c, "lossy_chain", [&] { return launch_lossy_chain(A, c->stream); });
+    }
+    // frame-parallel form
+    if (!b->d_at) {
+        size_t n = (size_t)b->total_frames * b->ch * 32 * sizeof(float);
+        HIPCHK(c, hipMalloc(&b->d_at, n));
+        HIPCHK(c, hipMalloc(&b->d_sprev, n));
+        HIPCHK(c, hipMalloc(&b->d_slots, (size_t)b->total_frames * kFrameCap));
+        HIPCHK(c, hipMalloc(&b->d_frame_off, (size_t)(b->total_frames + 1) * 8));
+    }
+    LossyArgs A = make_args(b);
+    int rc;
+    if ((rc = timed_launch(c, "lossy_bands", [&] { return launch_lossy_frames_pass(A, 1, c->stream); })) != FLO_OK) return rc;
+    if ((rc = timed_launch(c, "lossy_scan", [&] { return launch_lossy_scan(A, c->stream); })) != FLO_OK) return rc;
+    if ((rc = timed_launch(c, "lossy_frames", [&] { return launch_lossy_frames_pass(A, 2, c->stream); })) != FLO_OK) return rc;
+    if ((rc = timed_launch(c, "lossy_compact", [&] { return launch_lossy_compact(A, c->stream); })) != FLO_OK) return rc;
+    return FLO_OK;
+}
+
+extern "C" int flo_batch_sync(flo_batch *b) {
+    if (!b) return FLO_ERR_ARG;
+    flo_ctx *c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (b->encoded && !b->synced) {
+        if (b->mode == FLO_MODE_LOSSY) {
+            b->h_clip_bytes.assign(b->n_clips, 0);
+            b->h_frame_size.assign(b->total_frames, 0);
+            if (b->n_clips && b->total_frames) {
+                HIPCHK(c, hipMemcpy(b->h_clip_bytes.data(), b->d_clip_bytes, b->n_clips * 8, hipMemcpyDeviceToHost));
+                HIPCHK(c, hipMemcpy(b->h_frame_size.data(), b->d_frame_size, b->total_frames * 4, hipMemcpyDeviceToHost));
+            }
+            for (size_t i = 0; i < b->n_clips; i++)
+                if (b->h_clip_bytes[i] > b->out_cap[i]) return fail(c, FLO_ERR_DEVICE, "bitstream overran its buffer");
+        } else {
+            std::string err;
+            if (lossless_collect(b->ll, err) != 0) return fail(c, FLO_ERR_DEVICE, "lossless collect: " + err);
+        }
+        b->synced = true;
+    }
+    return FLO_OK;
+}
+
+extern "C" int flo_batch_data_bytes(flo_batch *b, uint64_t *total) {
+    if (!b || !total) return FLO_ERR_ARG;
+    if (!b->synced) return fail(b->ctx, FLO_ERR_STATE, "call flo_batch_encode + flo_batch_sync first");
+    uint64_t t = 0;
+    if (b->mode == FLO_MODE_LOSSY)
+        for (auto v : b->h_clip_bytes) t += v;
+    else
+        t = lossless_total_bytes(b->ll);
+    *total = t;
+    return FLO_OK;
+}
+
+extern "C" int flo_batch_device_streams(flo_batch *b, const uint8_t **base, const uint64_t **offsets,
+                                        const uint64_t **sizes) {
+    if (!b) return FLO_ERR_ARG;
+    if (!b->synced) return fail(b->ctx, FLO_ERR_STATE, "call flo_batch_encode + flo_batch_sync first");
+    if (b->mode == FLO_MODE_LOSSY) {
+        if (base) *base = b->d_out;
+        if (offsets) *offsets = b->out_off.data();
+        if (sizes) *sizes = b->h_clip_bytes.data();
+        return FLO_OK;
+    }
+    return lossless_device_streams(b->ll, base, offsets, sizes) == 0 ? FLO_OK : FLO_ERR_STATE;
+}
+
+extern "C" int flo_batch_fetch(flo_batch *b, size_t clip, const uint8_t *meta, size_t meta_len, uint8_t **out,
+                               size_t *out_len) {
+    if (!b || clip >= b->n_clips || !out || !out_len || (meta_len && !meta)) return FLO_ERR_ARG;
+    flo_ctx *c = b->ctx;
+    if (!b->synced) return fail(c, FLO_ERR_STATE, "call flo_batch_encode + flo_batch_sync first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->mode == FLO_MODE_LOSSLESS) {
+        std::string err;
+        int rc = lossless_fetch(b->ll, clip, b->bit_depth, meta, meta_len, out, out_len, err);
+        return rc == 0 ? FLO_OK : fail(c, FLO_ERR_DEVICE, "lossless fetch: " + err);
+    }
+    const size_t n = (size_t)b->h_clip_bytes[clip];
+    std::vector<uint8_t> data(n);
+    if (n) HIPCHK(c, hipMemcpy(data.data(), b->d_out + b->out_off[clip], n, hipMemcpyDeviceToHost));
+    const uint32_t hops = b->hops[clip];
+    std::vector<uint32_t> fsamp(hops, 1024);
+    FileParams fp{b->sr, b->ch, 16, 5, true, b->ts->host.q_level};  // encoder.rs:229-238
+    uint8_t *f = assemble_file(fp, data.data(), n, b->h_frame_size.data() + b->clip_frame0[clip], fsamp.data(), hops,
+                               meta, meta_len, out_len);
+    if (!f) return fail(c, FLO_ERR_NOMEM, "malloc failed");
+    *out = f;
+    return FLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ one-shot API
+extern "C" int flo_encode_batch(flo_ctx *c, int mode, size_t n_clips, const float *const *pcm, const size_t *n_il,
+                                uint32_t sr, uint8_t ch, float qol, uint8_t **outs, size_t *out_lens) {
+    if (!c || (n_clips && (!pcm || !n_il || !outs || !out_lens))) return FLO_ERR_ARG;
+    flo_batch *b = nullptr;
+    int rc = flo_batch_create(c, mode, n_clips, n_il, sr, ch, qol, &b);
+    if (rc != FLO_OK) return rc;
+    for (size_t i = 0; i < n_clips && rc == FLO_OK; i++) rc = flo_batch_upload(b, i, pcm[i]);
+    if (rc == FLO_OK) rc = flo_batch_encode(b, 0);
+    if (rc == FLO_OK) rc = flo_batch_sync(b);
+    for (size_t i = 0; i < n_clips; i++) outs[i] = nullptr;
+    for (size_t i = 0; i < n_clips && rc == FLO_OK; i++) rc = flo_batch_fetch(b, i, nullptr, 0, &outs[i], &out_lens[i]);
+    if (rc != FLO_OK)
+        for (size_t i = 0; i < n_clips; i++) {
+            free(outs[i]);
+            outs[i] = nullptr;
+        }
+    flo_batch_destroy(b);
+    return rc;
+}
+
+static int encode_one(flo_ctx *c, int mode, const float *pcm, size_t n, uint32_t sr, uint8_t ch, float qol,
+                      uint8_t bit_depth, const uint8_t *meta, size_t meta_len, uint8_t **out, size_t *out_len) {
+    if (!c || !out || !out_len || (n && !pcm) || (meta_len && !meta)) return FLO_ERR_ARG;
+    flo_batch *b = nullptr;
+    int rc = flo_batch_create(c, mode, 1, &n, sr, ch, qol, &b);
+    if (rc != FLO_OK) return rc;
+    b->bit_depth = bit_depth;
+    rc = flo_batch_upload(b, 0, pcm);
+    if (rc == FLO_OK) rc = flo_batch_encode(b, 0);
+    if (rc == FLO_OK) rc = flo_batch_sync(b);
+    if (rc == FLO_OK) rc = flo_batch_fetch(b, 0, meta, meta_len, out, out_len);
+    flo_batch_destroy(b);
+    return rc;
+}
+
+extern "C" int flo_encode_lossy(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, uint8_t ch, float quality,
+                                const uint8_t *meta, size_t meta_len, uint8_t **out, size_t *out_len) {
+    return encode_one(c, FLO_MODE_LOSSY, pcm, n, sr, ch, quality, 16, meta, meta_len, out, out_len);
+}
+extern "C" int flo_encode_lossless(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, uint8_t ch, uint8_t bit_depth,
+                                   uint8_t level, const uint8_t *meta, size_t meta_len, uint8_t **out,
+                                   size_t *out_len) {
+    return encode_one(c, FLO_MODE_LOSSLESS, pcm, n, sr, ch, (float)level, bit_depth, meta, meta_len, out, out_len);
+}
+
+// ------------------------------------------------------------------------------------------------ stage entry points
+extern "C" int flo_mdct_forward(flo_ctx *c, const float *frames, size_t n_frames, float *coeffs) {
+    if (!c || (n_frames && (!frames || !coeffs))) return FLO_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!n_frames) return FLO_OK;
+    TableSet *ts;
+    int rc = get_tables(c, 44100, 0.55f, &ts);
+    if (rc != FLO_OK) return rc;
+    float *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(c, hipMalloc(&d_in, n_frames * 2048 * sizeof(float)));
+    hipError_t e = hipMalloc(&d_out, n_frames * 1024 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, frames, n_frames * 2048 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    int lrc = 0;
+    if (e == hipSuccess) lrc = launch_mdct_only(ts->dev, d_in, n_frames, d_out, c->stream);
+    if (e == hipSuccess && lrc == 0)
+        e = hipMemcpyAsync(coeffs, d_out, n_frames * 1024 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    hipFree(d_in);
+    if (d_out) hipFree(d_out);
+    if (e != hipSuccess || e2 != hipSuccess || lrc != 0)
+        return fail(c, FLO_ERR_DEVICE, std::string("flo_mdct_forward: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return FLO_OK;
+}
+
+static int analyze_common(flo_ctx *c, const float *pcm, size_t n, const float *in_coeffs, size_t in_hops, uint32_t sr,
+                          uint8_t ch, float quality, float *coeffs, int16_t *q, uint16_t *sfw, size_t *num_hops) {
+    flo_batch *b = nullptr;
+    size_t n_il = in_coeffs ? (in_hops ? (in_hops - 1) * 1024 * ch : 0) : n;
+    if (in_coeffs && in_hops == 0) return FLO_OK;
+    int rc = flo_batch_create(c, FLO_MODE_LOSSY, 1, &n_il, sr, ch, quality, &b);
+    if (rc != FLO_OK) return rc;
+    const size_t hops = b->hops[0];
+    if (num_hops) *num_hops = hops;
+    float *d_in = nullptr;
+    auto done = [&](int code) {
+        if (d_in) hipFree(d_in);
+        flo_batch_destroy(b);
+        return code;
+    };
+    const size_t per = hops * ch;
+    if (hipMalloc(&b->d_dbg_coeffs, per * 1024 * 4 + 16) != hipSuccess || hipMalloc(&b->d_dbg_q, per * 1024 * 2 + 16) != hipSuccess ||
+        hipMalloc(&b->d_dbg_sfw, per * 25 * 2 + 16) != hipSuccess)
+        return done(fail(c, FLO_ERR_NOMEM, "hipMalloc analysis buffers"));
+    if (in_coeffs) {
+        if (hipMalloc(&d_in, per * 1024 * 4) != hipSuccess) return done(fail(c, FLO_ERR_NOMEM, "hipMalloc"));
+        if (hipMemcpy(d_in, in_coeffs, per * 1024 * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return done(fail(c, FLO_ERR_DEVICE, "hipMemcpy"));
+        b->d_in_coeffs = d_in;
+    } else {
+        rc = flo_batch_upload(b, 0, pcm);
+        if (rc != FLO_OK) return done(rc);
+    }
+    rc = flo_batch_encode(b, c->force_path ? c->force_path : 1);
+    if (rc == FLO_OK) rc = flo_batch_sync(b);
+    if (rc != FLO_OK) return done(rc);
+    hipError_t e = hipSuccess;
+    if (coeffs && !in_coeffs) e = hipMemcpy(coeffs, b->d_dbg_coeffs, per * 1024 * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && q) e = hipMemcpy(q, b->d_dbg_q, per * 1024 * 2, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && sfw) e = hipMemcpy(sfw, b->d_dbg_sfw, per * 25 * 2, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return done(fail(c, FLO_ERR_DEVICE, std::string("analysis D2H: ") + hipGetErrorString(e)));
+    return done(FLO_OK);
+}
+
+extern "C" int flo_lossy_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, uint8_t ch, float quality,
+                                 float *coeffs, int16_t *q, uint16_t *sfw, size_t *num_hops) {
+    if (!c || (n && !pcm)) return FLO_ERR_ARG;
+    return analyze_common(c, pcm, n, nullptr, 0, sr, ch, quality, coeffs, q, sfw, num_hops);
+}
+extern "C" int flo_lossy_quantize(flo_ctx *c, const float *coeffs, size_t num_hops, uint32_t sr, uint8_t ch,
+                                  float quality, int16_t *q, uint16_t *sfw) {
+    if (!c || (num_hops && !coeffs)) return FLO_ERR_ARG;
+    return analyze_common(c, nullptr, 0, coeffs, num_hops, sr, ch, quality, nullptr, q, sfw, nullptr);
+}
+
+extern "C" int flo_sparse_pack(flo_ctx *c, const int16_t *q, size_t n_vec, uint8_t *out, size_t out_cap,
+                               uint32_t *out_off) {
+    if (!c || (n_vec && (!q || !out || !out_off))) return FLO_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (out_off) out_off[0] = 0;
+    if (!n_vec) return FLO_OK;
+    short *d_q = nullptr;
+    uint8_t *d_slots = nullptr;
+    uint32_t *d_sizes = nullptr;
+    HIPCHK(c, hipMalloc(&d_q, n_vec * 2048));
+    hipError_t e = hipMalloc(&d_slots, n_vec * 2080);
+    if (e == hipSuccess) e = hipMalloc(&d_sizes, n_vec * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_q, q, n_vec * 2048, hipMemcpyHostToDevice, c->stream);
+    int lrc = 0;
+    if (e == hipSuccess) lrc = launch_sparse_only(d_q, n_vec, d_slots, d_sizes, c->stream);
+    std::vector<uint8_t> slots(n_vec * 2080);
+    std::vector<uint32_t> sizes(n_vec);
+    if (e == hipSuccess && lrc == 0) e = hipMemcpyAsync(slots.data(), d_slots, slots.size(), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && lrc == 0) e = hipMemcpyAsync(sizes.data(), d_sizes, n_vec * 4, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    hipFree(d_q);
+    if (d_slots) hipFree(d_slots);
+    if (d_sizes) hipFree(d_sizes);
+    if (e != hipSuccess || e2 != hipSuccess || lrc != 0) return fail(c, FLO_ERR_DEVICE, "flo_sparse_pack failed");
+    size_t pos = 0;
+    for (size_t i = 0; i < n_vec; i++) {
+        if (pos + sizes[i] > out_cap) return fail(c, FLO_ERR_ARG, "output buffer too small");
+        memcpy(out + pos, slots.data() + i * 2080, sizes[i]);
+        pos += sizes[i];
+        out_off[i + 1] = (uint32_t)pos;
+    }
+    return FLO_OK;
+}

@@ -1,0 +1,458 @@
+// lossy_kernels.hip — gfx950 kernels of the lossy encode path and their launchers.
+//
+//   lossy_chain_kernel<CH>   one wavefront per clip walks the clip's frames in order (the psychoacoustic
+//                            model's 25-float temporal state, psychoacoustic.rs:198-203, lives in registers),
+//                            reads every PCM sample once and appends finished frame bytes to the clip's DATA
+//                            chunk: replaces the hot loop of TransformEncoder::encode_to_flo (encoder.rs:200-225).
+//   lossy_frame_kernel<CH,P> frame-parallel form for few/long clips: P=1 computes only the per-band masking
+//                            level before temporal masking, lossy_scan_kernel resolves the recurrence, P=2
+//                            re-runs the transform and finishes each frame into a fixed slot; compact_kernel
+//                            packs the slots. Both forms produce identical bytes.
+#include "lossy_device.hpp"
+#include "lossy_kernels.hpp"
+#include "../../include/flo_synth.h"
+
+namespace flo {
+
+// ---------------------------------------------------------------------------------------------- frame body
+template <int CH>
+struct FrameState {
+    float prev[CH];  // lanes 0..24: temporal masking state of band `lane`
+};
+
+// Everything after the MDCT for one frame of CH channels. c = coefficients (contiguous layout).
+// Returns the frame length in bytes; the frame is assembled in lds.u.stage at byte offset `pend`.
+template <int CH, bool BANDS_ONLY>
+__device__ __forceinline__ uint32_t finish_frame(float (&c)[CH][16], LossyLds<CH> &lds, const LaneConst &L,
+                                                 const LossyArgs &A, FrameState<CH> &st, uint32_t pend,
+                                                 uint32_t tailbyte, unsigned long long gframe, int16_t *qbuf) {
+    const int lane = lane_id();
+    const LossyDevTables &T = A.T;
+    float energy[CH], bmax[CH];
+    band_stats<CH>(c, lds.slots, L, T.max_band_slots, energy, bmax);
+
+    uint32_t sfw[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+        float a = spread_threshold(energy[ch], L.bcount, T);
+        if (BANDS_ONLY) {
+            if (lane < 25) A.a_t[(gframe * A.nch + ch) * 32 + lane] = a;
+            continue;
+        }
+        // temporal masking (psychoacoustic.rs:196-203)
+        float s = fmaxf(a, st.prev[ch] * 0.7f);
+        st.prev[ch] = s;
+        // amplitude-domain threshold of the masking level: 10^((smr_thr + fl(s - 10)) / 20)
+        float thr_db = s - 10.0f;
+        float tlin = exp10f((T.smr_thr + thr_db) * 0.05f);
+        // scale factor (encoder.rs:121-127)
+        float sf = bmax[ch] > 1e-10f ? 30000.0f / bmax[ch] : 1.0f;
+        sfw[ch] = sf_word(sf);
+        if (lane < 25) lds.bandv[ch][lane] = make_float4(tlin, sf, s, 0.f);
+    }
+    if (BANDS_ONLY) return 0;
+    __syncthreads();
+
+    int q[CH][16];
+    quantise<CH>(c, lds.bandv, L, T, q);
+
+    // dense outputs for the analysis entry points
+    if (A.dbg_q) {
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) {
+            short *dq = A.dbg_q + (gframe * A.nch + ch) * 1024 + 16 * lane;
+#pragma unroll
+            for (int e = 0; e < 16; e++) dq[e] = (short)q[ch][e];
+        }
+    }
+    if (A.dbg_sfw && lane < 25) {
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) A.dbg_sfw[(gframe * A.nch + ch) * 25 + lane] = (unsigned short)sfw[ch];
+    }
+
+    SparsePlan P[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+        sparse_plan(q[ch], P[ch]);
+        // values are fetched by run-time position while emitting: park them in LDS
+        uint32_t *qb = reinterpret_cast<uint32_t *>(qbuf + ch * 1024 + 16 * lane);
+#pragma unroll
+        for (int e = 0; e < 8; e++) qb[e] = ((uint32_t)q[ch][2 * e] & 0xFFFFu) | ((uint32_t)q[ch][2 * e + 1] << 16);
+    }
+    __syncthreads();
+
+    // ---- assemble the frame bytes (writer.rs:236-254 + encoder.rs:243-280) in LDS ----
+    uint8_t *stg = lds.u.stage;
+    if (lane < (int)pend) stg[lane] = (uint8_t)tailbyte;
+    uint8_t *f = stg + pend;
+    uint32_t pos = 12 + 50 * CH;  // first sparse length field
+    uint32_t chpos[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+        chpos[ch] = pos;
+        pos += 4 + P[ch].total;
+    }
+    const uint32_t flen = pos;
+    const uint32_t blob_len = flen - 10;
+    if (lane == 0) {
+        f[0] = 253;
+        f[1] = 0x00; f[2] = 0x04; f[3] = 0; f[4] = 0;  // frame_samples = 1024
+        f[5] = 0;
+        f[6] = (uint8_t)blob_len; f[7] = (uint8_t)(blob_len >> 8); f[8] = (uint8_t)(blob_len >> 16); f[9] = (uint8_t)(blob_len >> 24);
+        f[10] = 0;  // BlockSize::Long
+        f[11] = (uint8_t)CH;
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) {
+            uint32_t l = P[ch].total;
+            uint8_t *p = f + chpos[ch];
+            p[0] = (uint8_t)l; p[1] = (uint8_t)(l >> 8); p[2] = (uint8_t)(l >> 16); p[3] = (uint8_t)(l >> 24);
+        }
+    }
+    if (lane < 25) {
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) {
+            f[12 + 50 * ch + 2 * lane] = (uint8_t)sfw[ch];
+            f[12 + 50 * ch + 2 * lane + 1] = (uint8_t)(sfw[ch] >> 8);
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+        sparse_emit(qbuf + ch * 1024 + 16 * lane, P[ch], f + chpos[ch] + 4);
+    }
+    __syncthreads();
+    return flen;
+}
+
+// MDCT of one frame of CH channels: halves (ae,ao) + (be,bo) -> c (contiguous layout)
+template <int CH>
+__device__ __forceinline__ void mdct_frame(const float (&ae)[CH][8], const float (&ao)[CH][8],
+                                           const float (&be)[CH][8], const float (&bo)[CH][8], LossyLds<CH> &lds,
+                                           const LossyDevTables &T, float (&c)[CH][16]) {
+    float zr[CH][8], zi[CH][8];
+    fold<CH>(ae, ao, be, bo, zr, zi, T);
+    fft512<CH>(zr, zi, lds.u.xch, T);
+    post_rotate_transpose<CH>(zr, zi, lds.u.coef, c, T);
+}
+
+template <int CH>
+__device__ __forceinline__ void store_coeffs_dbg(const float (&c)[CH][16], const LossyArgs &A,
+                                                 unsigned long long gframe) {
+    if (!A.dbg_coeffs) return;
+    const int lane = lane_id();
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+        float4 *d = reinterpret_cast<float4 *>(A.dbg_coeffs + (gframe * A.nch + ch) * 1024 + 16 * lane);
+#pragma unroll
+        for (int q = 0; q < 4; q++) d[q] = make_float4(c[ch][4 * q], c[ch][4 * q + 1], c[ch][4 * q + 2], c[ch][4 * q + 3]);
+    }
+}
+
+template <int CH>
+__device__ __forceinline__ void load_coeffs(float (&c)[CH][16], const LossyArgs &A, unsigned long long gframe) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+        const float4 *s = reinterpret_cast<const float4 *>(A.in_coeffs + (gframe * A.nch + ch) * 1024 + 16 * lane);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float4 v = s[q];
+            c[ch][4 * q] = v.x; c[ch][4 * q + 1] = v.y; c[ch][4 * q + 2] = v.z; c[ch][4 * q + 3] = v.w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- chain kernel
+// Add an opaque zero to the table pointers once per frame: the loads then depend on a value the compiler cannot
+// see through, so they stay inside the frame loop (served by L1/L2) instead of being hoisted into ~100 registers.
+// The pointers keep their global address space (laundering the pointer itself degrades them to flat loads).
+__device__ __forceinline__ void launder_tables(LossyDevTables &T) {
+    unsigned zero = 0;
+    asm volatile("" : "+s"(zero));
+    T.pack += zero;
+    T.ath_db += zero;
+    T.s10d += zero;
+}
+
+template <int CH>
+__global__ __launch_bounds__(64) void lossy_chain_kernel(LossyArgs A) {
+    __shared__ LossyLds<CH> lds;
+    __shared__ int16_t qbuf[CH * 1024];
+    const int lane = lane_id();
+    const unsigned clip = blockIdx.x;
+    if (clip >= (unsigned)A.n_clips) return;
+    const float *pcm = A.pcm + A.clip_off[clip];
+    const long long n_sf = (long long)A.clip_nsf[clip];
+    const unsigned hops = A.clip_hops[clip];
+    const unsigned long long frame0 = A.clip_frame0[clip];
+    uint8_t *gout = A.out + A.out_off[clip];
+
+    LaneConst L;
+    load_lane_const(L, A.T);
+    FrameState<CH> st;
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) st.prev[ch] = 0.f;
+
+    float ae[CH][8], ao[CH][8], be[CH][8], bo[CH][8];
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) ae[ch][r] = ao[ch][r] = 0.f;  // pre-roll: 1024 zeros (encoder.rs:177)
+    if (!A.in_coeffs) load_half<CH>(pcm, n_sf, A.nch, 0, 0, be, bo);
+
+    unsigned long long written = 0;
+    uint32_t pend = 0, tailbyte = 0;
+    for (unsigned h = 0; h < hops; h++) {
+        // Keep the constant tables in cache, not in registers: without this the compiler hoists ~100 loop-invariant
+        // table loads out of the frame loop and the kernel drops to one wave per SIMD.
+        launder_tables(A.T);
+        float c[CH][16];
+        if (A.in_coeffs) {
+            load_coeffs<CH>(c, A, frame0 + h);
+        } else {
+            float zr[CH][8], zi[CH][8];
+            fold<CH>(ae, ao, be, bo, zr, zi, A.T);
+#pragma unroll
+            for (int ch = 0; ch < CH; ch++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    ae[ch][r] = be[ch][r];
+                    ao[ch][r] = bo[ch][r];
+                }
+            // issue the next half-frame's loads now; they are consumed at the top of the next iteration
+            if (h + 1 < hops) load_half<CH>(pcm, n_sf, A.nch, 0, (long long)(h + 1) * 1024, be, bo);
+            fft512<CH>(zr, zi, lds.u.xch, A.T);
+            post_rotate_transpose<CH>(zr, zi, lds.u.coef, c, A.T);
+            store_coeffs_dbg<CH>(c, A, frame0 + h);
+        }
+        const uint32_t flen = finish_frame<CH, false>(c, lds, L, A, st, pend, tailbyte, frame0 + h, qbuf);
+        if (lane == 0) A.frame_size[frame0 + h] = flen;
+        // flush complete 16-byte chunks, carry the rest
+        const uint32_t have = pend + flen;
+        const uint32_t n16 = have >> 4;
+        const uint4 *src = reinterpret_cast<const uint4 *>(lds.u.stage);
+        uint4 *dst = reinterpret_cast<uint4 *>(gout + written);
+        for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
+        pend = have & 15u;
+        tailbyte = (lane < (int)pend) ? lds.u.stage[(n16 << 4) + lane] : 0u;
+        written += (unsigned long long)n16 << 4;
+        __syncthreads();
+    }
+    if (lane < (int)pend) gout[written + lane] = (uint8_t)tailbyte;
+    if (lane == 0) A.clip_bytes[clip] = written + pend;
+}
+
+// ---------------------------------------------------------------------------------------------- frame-parallel
+// PASS 1: a_t only. PASS 2: full frame into slot gframe.
+template <int CH, int PASS>
+__global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
+    __shared__ LossyLds<CH> lds;
+    __shared__ int16_t qbuf[CH * 1024];
+    const int lane = lane_id();
+    const unsigned long long gframe = blockIdx.x;
+    if (gframe >= A.total_frames) return;
+    // locate clip by binary search over clip_frame0
+    int lo = 0, hi = A.n_clips - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (A.clip_frame0[mid] <= gframe) lo = mid; else hi = mid - 1;
+    }
+    const unsigned clip = (unsigned)lo;
+    const unsigned h = (unsigned)(gframe - A.clip_frame0[clip]);
+    const float *pcm = A.pcm + A.clip_off[clip];
+    const long long n_sf = (long long)A.clip_nsf[clip];
+
+    LaneConst L;
+    load_lane_const(L, A.T);
+    float c[CH][16];
+    if (A.in_coeffs) {
+        load_coeffs<CH>(c, A, gframe);
+    } else {
+        float ae[CH][8], ao[CH][8], be[CH][8], bo[CH][8];
+        load_half<CH>(pcm, n_sf, A.nch, 0, (long long)h * 1024 - 1024, ae, ao);
+        load_half<CH>(pcm, n_sf, A.nch, 0, (long long)h * 1024, be, bo);
+        mdct_frame<CH>(ae, ao, be, bo, lds, A.T, c);
+    }
+    FrameState<CH> st;
+    if (PASS == 1) {
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) st.prev[ch] = 0.f;
+        finish_frame<CH, true>(c, lds, L, A, st, 0, 0, gframe, qbuf);
+        return;
+    }
+    store_coeffs_dbg<CH>(c, A, gframe);
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) st.prev[ch] = lane < 25 ? A.s_prev[(gframe * A.nch + ch) * 32 + lane] : 0.f;
+    const uint32_t flen = finish_frame<CH, false>(c, lds, L, A, st, 0, 0, gframe, qbuf);
+    if (lane == 0) A.frame_size[gframe] = flen;
+    const uint32_t n16 = (flen + 15) >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(lds.u.stage);
+    uint4 *dst = reinterpret_cast<uint4 *>(A.slots + gframe * (unsigned long long)kFrameCap);
+    for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
+}
+
+// temporal recurrence s_t = max(a_t, 0.7 s_{t-1}), s_{-1} = 0 (psychoacoustic.rs:198-203): one thread per
+// (clip, channel, band) walks the clip's frames; writes the state seen BEFORE each frame.
+__global__ void lossy_scan_kernel(LossyArgs A) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned per_clip = (unsigned)A.nch * 32u;
+    const unsigned clip = t / per_clip;
+    if (clip >= (unsigned)A.n_clips) return;
+    const unsigned rem = t % per_clip;
+    const unsigned ch = rem >> 5, band = rem & 31u;
+    if (band >= 25) return;
+    const unsigned long long f0 = A.clip_frame0[clip];
+    const unsigned hops = A.clip_hops[clip];
+    float s = 0.f;
+    for (unsigned h = 0; h < hops; h++) {
+        const unsigned long long idx = ((f0 + h) * A.nch + ch) * 32 + band;
+        A.s_prev_out[idx] = s;
+        s = fmaxf(A.a_t[idx], s * 0.7f);
+    }
+}
+
+// pack the fixed-size slots of one clip into its DATA chunk: one workgroup per frame
+__global__ void lossy_compact_kernel(LossyArgs A) {
+    const unsigned long long gframe = blockIdx.x;
+    if (gframe >= A.total_frames) return;
+    int lo = 0, hi = A.n_clips - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (A.clip_frame0[mid] <= gframe) lo = mid; else hi = mid - 1;
+    }
+    const unsigned clip = (unsigned)lo;
+    const unsigned long long off = A.frame_off[gframe];  // byte offset inside the clip's DATA chunk
+    const uint32_t len = A.frame_size[gframe];
+    const uint8_t *src = A.slots + gframe * (unsigned long long)kFrameCap;
+    uint8_t *dst = A.out + A.out_off[clip] + off;
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
+}
+
+// exclusive scan of frame sizes inside each clip (one thread per clip; clips here are few and long)
+__global__ void lossy_frame_offsets_kernel(LossyArgs A) {
+    const unsigned clip = blockIdx.x * blockDim.x + threadIdx.x;
+    if (clip >= (unsigned)A.n_clips) return;
+    const unsigned long long f0 = A.clip_frame0[clip];
+    const unsigned hops = A.clip_hops[clip];
+    unsigned long long off = 0;
+    for (unsigned h = 0; h < hops; h++) {
+        A.frame_off[f0 + h] = off;
+        off += A.frame_size[f0 + h];
+    }
+    A.clip_bytes[clip] = off;
+}
+
+// ---------------------------------------------------------------------------------------------- stage kernels
+// forward MDCT of independent 2048-sample mono windows (flo_mdct_forward)
+__global__ __launch_bounds__(64) void mdct_only_kernel(LossyDevTables T, const float *frames, unsigned long long n,
+                                                       float *out) {
+    __shared__ LossyLds<1> lds;
+    const unsigned long long w = blockIdx.x;
+    if (w >= n) return;
+    const int lane = lane_id();
+    float ae[1][8], ao[1][8], be[1][8], bo[1][8];
+    const float *p = frames + w * 2048;
+    load_half<1>(p, 2048, 1, 0, 0, ae, ao);
+    load_half<1>(p, 2048, 1, 0, 1024, be, bo);
+    float c[1][16];
+    mdct_frame<1>(ae, ao, be, bo, lds, T, c);
+    float4 *d = reinterpret_cast<float4 *>(out + w * 1024 + 16 * lane);
+#pragma unroll
+    for (int q = 0; q < 4; q++) d[q] = make_float4(c[0][4 * q], c[0][4 * q + 1], c[0][4 * q + 2], c[0][4 * q + 3]);
+}
+
+// serialize_sparse of independent 1024-value vectors into fixed slots (flo_sparse_pack)
+__global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigned long long n, uint8_t *slots,
+                                                         uint32_t *sizes) {
+    __shared__ uint8_t stage[2080];
+    __shared__ int16_t qb[1024];
+    const unsigned long long w = blockIdx.x;
+    if (w >= n) return;
+    const int lane = lane_id();
+    int v[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        v[e] = q[w * 1024 + 16 * lane + e];
+        qb[16 * lane + e] = (int16_t)v[e];
+    }
+    SparsePlan P;
+    sparse_plan(v, P);
+    __syncthreads();
+    sparse_emit(qb + 16 * lane, P, stage);
+    __syncthreads();
+    for (uint32_t i = lane; i < P.total; i += 64) slots[w * 2080 + i] = stage[i];
+    if (lane == 0) sizes[w] = P.total;
+}
+
+// integer-exact synthetic PCM (include/flo_synth.h), one thread per 4 interleaved samples
+__global__ void synth_fill_kernel(float *pcm, const unsigned long long *clip_off, const unsigned long long *clip_nsf,
+                                  int n_clips, int nch, uint32_t seed, unsigned long long clip_id0) {
+    const unsigned clip = blockIdx.y;
+    if (clip >= (unsigned)n_clips) return;
+    const unsigned long long n = clip_nsf[clip] * (unsigned long long)nch;
+    float *p = pcm + clip_off[clip];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long sf = i / (unsigned)nch;
+        const unsigned ch = (unsigned)(i % (unsigned)nch);
+        p[i] = flo_synth_sample(seed, clip_id0 + clip, ch, sf);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+#define FLO_LAUNCH_CHECK()                     \
+    do {                                       \
+        hipError_t e_ = hipGetLastError();     \
+        if (e_ != hipSuccess) return (int)e_;  \
+    } while (0)
+
+int launch_lossy_chain(const LossyArgs &A, hipStream_t s) {
+    if (A.nch == 1) hipLaunchKernelGGL(lossy_chain_kernel<1>, dim3(A.n_clips), dim3(64), 0, s, A);
+    else if (A.nch == 2) hipLaunchKernelGGL(lossy_chain_kernel<2>, dim3(A.n_clips), dim3(64), 0, s, A);
+    else return -1;
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s) {
+    dim3 g((unsigned)A.total_frames), b(64);
+    if (A.nch == 1) {
+        if (pass == 1) hipLaunchKernelGGL((lossy_frame_kernel<1, 1>), g, b, 0, s, A);
+        else hipLaunchKernelGGL((lossy_frame_kernel<1, 2>), g, b, 0, s, A);
+    } else if (A.nch == 2) {
+        if (pass == 1) hipLaunchKernelGGL((lossy_frame_kernel<2, 1>), g, b, 0, s, A);
+        else hipLaunchKernelGGL((lossy_frame_kernel<2, 2>), g, b, 0, s, A);
+    } else return -1;
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_lossy_scan(const LossyArgs &A, hipStream_t s) {
+    unsigned threads = (unsigned)A.n_clips * (unsigned)A.nch * 32u;
+    hipLaunchKernelGGL(lossy_scan_kernel, dim3((threads + 63) / 64), dim3(64), 0, s, A);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_lossy_compact(const LossyArgs &A, hipStream_t s) {
+    hipLaunchKernelGGL(lossy_frame_offsets_kernel, dim3((A.n_clips + 63) / 64), dim3(64), 0, s, A);
+    FLO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lossy_compact_kernel, dim3((unsigned)A.total_frames), dim3(256), 0, s, A);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_mdct_only(const LossyDevTables &T, const float *frames, unsigned long long n, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(mdct_only_kernel, dim3((unsigned)n), dim3(64), 0, s, T, frames, n, out);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_sparse_only(const short *q, unsigned long long n, uint8_t *slots, uint32_t *sizes, hipStream_t s) {
+    hipLaunchKernelGGL(sparse_only_kernel, dim3((unsigned)n), dim3(64), 0, s, q, n, slots, sizes);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_synth_fill(float *pcm, const unsigned long long *clip_off, const unsigned long long *clip_nsf, int n_clips,
+                      int nch, uint32_t seed, unsigned long long clip_id0, hipStream_t s) {
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(64, n_clips), dim3(256), 0, s, pcm, clip_off, clip_nsf, n_clips, nch,
+                       seed, clip_id0);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace flo

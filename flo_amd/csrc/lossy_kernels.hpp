@@ -1,0 +1,48 @@
+// lossy_kernels.hpp — kernel argument block and launchers of the lossy path (see lossy_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lossy_device.hpp"
+
+namespace flo {
+
+struct LossyArgs {
+    LossyDevTables T;
+    // input
+    const float *pcm;                        // all clips, interleaved f32
+    const unsigned long long *clip_off;      // [n_clips] float offset of the clip (multiple of 4)
+    const unsigned long long *clip_nsf;      // [n_clips] sample-frames per clip
+    const unsigned int *clip_hops;           // [n_clips] frames per clip: ceil((nsf + 1024) / 1024)
+    const unsigned long long *clip_frame0;   // [n_clips] index of the clip's first frame among all frames
+    int nch;
+    int n_clips;
+    unsigned long long total_frames;
+    // output
+    uint8_t *out;                            // DATA chunks
+    const unsigned long long *out_off;       // [n_clips] byte offset of the clip's DATA chunk (16-byte aligned)
+    unsigned int *frame_size;                // [total_frames]
+    unsigned long long *clip_bytes;          // [n_clips] DATA chunk size
+    // frame-parallel form
+    float *a_t;                              // [total_frames][nch][32] masking level before temporal masking
+    float *s_prev_out;                       // [total_frames][nch][32] scan output
+    const float *s_prev;                     // same buffer, read by pass 2
+    uint8_t *slots;                          // [total_frames][kFrameCap]
+    unsigned long long *frame_off;           // [total_frames] offset of the frame inside its clip's DATA chunk
+    // analysis / stage tests (may be null)
+    float *dbg_coeffs;                       // [total_frames][nch][1024]
+    short *dbg_q;                            // [total_frames][nch][1024]
+    unsigned short *dbg_sfw;                 // [total_frames][nch][25]
+    const float *in_coeffs;                  // when set: skip the transform, quantise these spectra
+};
+
+int launch_lossy_chain(const LossyArgs &A, hipStream_t s);
+int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s);
+int launch_lossy_scan(const LossyArgs &A, hipStream_t s);
+int launch_lossy_compact(const LossyArgs &A, hipStream_t s);
+int launch_mdct_only(const LossyDevTables &T, const float *frames, unsigned long long n, float *out, hipStream_t s);
+int launch_sparse_only(const short *q, unsigned long long n, uint8_t *slots, uint32_t *sizes, hipStream_t s);
+int launch_synth_fill(float *pcm, const unsigned long long *clip_off, const unsigned long long *clip_nsf, int n_clips,
+                      int nch, uint32_t seed, unsigned long long clip_id0, hipStream_t s);
+
+}  // namespace flo

@@ -1,0 +1,127 @@
+/*
+ * flo_hip.h — C ABI of the MI355X-native flo encoder (libflo_hip.so).
+ *
+ * Drop-in boundary for libflo's per-clip encode path. Every entry point is `extern "C"`, takes plain
+ * pointers and sizes, and replaces one reference interface (cited as file:line under /root/reference):
+ *
+ *   flo_encode_lossy      <- lossy::TransformEncoder::new(sr,ch,q).encode_to_flo(samples, meta)
+ *                            libflo/src/lossy/encoder.rs:36-53,167-239 (re-exported as LossyEncoder, lib.rs:21-24)
+ *   flo_encode_lossless   <- lossless::Encoder::new(sr,ch,bits).with_compression(level).encode(samples, meta)
+ *                            libflo/src/lossless/encoder.rs:17-45
+ *   flo_encode_batch      <- the same two calls, once per clip (callers loop in reflo/src/lib.rs:286-306)
+ *   flo_free              <- drop of the returned Vec<u8>
+ *   error codes + flo_last_error <- FloResult<T> = Result<T, String>   (core/types.rs:281)
+ *
+ * Conventions mirror the reference: inputs are interleaved f32 PCM in [-1,1], length
+ * n_interleaved = sample_frames * channels (a trailing partial sample-frame is ignored, as the reference's
+ * integer division does); metadata is an opaque byte string appended verbatim as the META chunk; the output
+ * is one malloc'ed buffer holding a complete .flo file, released with flo_free. One flo_ctx per host
+ * thread / GPU; contexts are independent. A "fresh encoder per clip" is the contract for lossy encodes
+ * (the reference never resets the psychoacoustic state between calls; all its callers build a new encoder).
+ *
+ * There is NO CPU fallback: every encode entry point runs the HIP kernels on the context's device and
+ * fails with a non-zero code if no gfx950 device is usable.
+ */
+#ifndef FLO_HIP_H
+#define FLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLO_OK 0
+#define FLO_ERR_ARG 1      /* invalid argument */
+#define FLO_ERR_DEVICE 2   /* HIP runtime / device error (text in flo_last_error) */
+#define FLO_ERR_NOMEM 3
+#define FLO_ERR_STATE 4    /* call sequence error on a batch object */
+
+#define FLO_MODE_LOSSLESS 0
+#define FLO_MODE_LOSSY 1
+
+typedef struct flo_ctx flo_ctx; /* owns device id, stream, constant tables, scratch */
+
+int flo_ctx_create(int device, flo_ctx **out);
+void flo_ctx_destroy(flo_ctx *ctx);
+const char *flo_last_error(const flo_ctx *ctx); /* message of the last failing call on this ctx */
+/* message of the last failing flo_ctx_create (no ctx exists yet to hold it) */
+const char *flo_last_create_error(void);
+void flo_free(void *p);
+/* device facts for reports: name, CU count, total HBM bytes */
+int flo_ctx_device_info(const flo_ctx *ctx, char *name, size_t name_cap, int *compute_units, uint64_t *hbm_bytes);
+
+/* ---- one clip in, one .flo file out (host buffers; includes H2D/D2H) ------------------------------- */
+int flo_encode_lossy(flo_ctx *ctx, const float *pcm, size_t n_interleaved, uint32_t sample_rate, uint8_t channels,
+                     float quality, const uint8_t *meta, size_t meta_len, uint8_t **out, size_t *out_len);
+int flo_encode_lossless(flo_ctx *ctx, const float *pcm, size_t n_interleaved, uint32_t sample_rate,
+                        uint8_t channels, uint8_t bit_depth, uint8_t level, const uint8_t *meta, size_t meta_len,
+                        uint8_t **out, size_t *out_len);
+/* many clips in one launch sequence; outs[i]/out_lens[i] receive one malloc'ed .flo per clip */
+int flo_encode_batch(flo_ctx *ctx, int mode, size_t n_clips, const float *const *pcm, const size_t *n_interleaved,
+                     uint32_t sample_rate, uint8_t channels, float quality_or_level, uint8_t **outs,
+                     size_t *out_lens);
+
+/* ---- device-resident batch (the throughput path: PCM already in HBM, bitstreams left in HBM) -------- */
+typedef struct flo_batch flo_batch;
+
+/* Plan a batch: clip i has n_interleaved[i] samples. Allocates the HBM input buffer (clips back to back,
+ * each start 16-byte aligned), the output bitstream buffer and scratch. mode = FLO_MODE_LOSSY/LOSSLESS. */
+int flo_batch_create(flo_ctx *ctx, int mode, size_t n_clips, const size_t *n_interleaved, uint32_t sample_rate,
+                     uint8_t channels, float quality_or_level, flo_batch **out);
+void flo_batch_destroy(flo_batch *b);
+/* device pointer to clip i's interleaved f32 PCM (n_interleaved[i] floats) — fill it however you like */
+float *flo_batch_clip_device_ptr(flo_batch *b, size_t clip);
+/* H2D copy of one clip */
+int flo_batch_upload(flo_batch *b, size_t clip, const float *pcm);
+/* fill every clip with the integer-exact synthetic signal of flo_synth.h (device kernel), seeded by seed;
+ * clip ids start at clip_id0 so that ranks of a sharded job generate disjoint parts of one corpus */
+int flo_batch_fill_synthetic(flo_batch *b, uint32_t seed, uint64_t clip_id0);
+/* launch the encode kernels on the ctx stream (asynchronous). which = 0: auto, 1: force the clip-chain
+ * kernel, 2: force the frame-parallel kernels (lossy only; both produce identical bytes) */
+int flo_batch_encode(flo_batch *b, int which);
+int flo_batch_sync(flo_batch *b);
+/* after sync: total compressed DATA bytes of the batch, and of one clip */
+int flo_batch_data_bytes(flo_batch *b, uint64_t *total);
+/* D2H + container assembly (header, TOC, CRC32, META) of one clip -> malloc'ed .flo */
+int flo_batch_fetch(flo_batch *b, size_t clip, const uint8_t *meta, size_t meta_len, uint8_t **out,
+                    size_t *out_len);
+/* device address and size of the packed per-clip DATA chunks, for a zero-copy hand-off (e.g. an RCCL gather):
+ * clip i's DATA chunk is at base + offsets[i], sizes[i] bytes (both arrays host-side, n_clips entries) */
+int flo_batch_device_streams(flo_batch *b, const uint8_t **base, const uint64_t **offsets, const uint64_t **sizes);
+
+/* ---- measurement hooks ----------------------------------------------------------------------------- */
+/* When enabled, every launch of a named kernel on the ctx stream is bracketed by hipEvents on that stream. */
+int flo_ctx_profile_enable(flo_ctx *ctx, int on);
+/* sum and count of bracketed launches of `kernel` since the last reset (call after a sync) */
+int flo_ctx_profile_query(flo_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
+int flo_ctx_profile_reset(flo_ctx *ctx);
+/* test hook: force the lossy kernel form used by the one-shot entry points (0 auto, 1 chain, 2 frame-parallel) */
+int flo_ctx_force_path(flo_ctx *ctx, int which);
+/* stream handle (hipStream_t) of the context, for callers that enqueue their own work around the encode */
+void *flo_ctx_stream(flo_ctx *ctx);
+
+/* ---- stage-level entry points (parity tests call the kernels through these) -------------------------- */
+/* forward MDCT of n_frames windows of 2048 samples (mono, back to back) -> n_frames*1024 coefficients.
+ * Replaces Mdct::forward(samples, BlockSize::Long) with the Vorbis window — lossy/mdct.rs:337-347,166-226 */
+int flo_mdct_forward(flo_ctx *ctx, const float *frames, size_t n_frames, float *coeffs);
+/* per-frame intermediates of one clip's lossy encode, device path: arrays [hops][ch][1024] / [hops][ch][25];
+ * any pointer may be NULL. Replaces TransformEncoder::encode_frame — lossy/encoder.rs:63-106 */
+int flo_lossy_analyze(flo_ctx *ctx, const float *pcm, size_t n_interleaved, uint32_t sample_rate,
+                      uint8_t channels, float quality, float *coeffs, int16_t *quantized, uint16_t *sf_words,
+                      size_t *num_hops);
+/* quantise + serialise given MDCT coefficients (device quantiser fed caller-supplied spectra):
+ * coeffs [hops][ch][1024] -> quantized [hops][ch][1024], sf_words [hops][ch][25]. Replaces
+ * PsychoacousticModel::calculate_smr + TransformEncoder::quantize_coefficients
+ * (lossy/psychoacoustic.rs:151-235, lossy/encoder.rs:109-154) */
+int flo_lossy_quantize(flo_ctx *ctx, const float *coeffs, size_t num_hops, uint32_t sample_rate, uint8_t channels,
+                       float quality, int16_t *quantized, uint16_t *sf_words);
+/* serialize_sparse on device: n_vec vectors of 1024 i16 -> bytes; out_off[n_vec+1] prefix offsets.
+ * Replaces lossy/encoder.rs:284-314 */
+int flo_sparse_pack(flo_ctx *ctx, const int16_t *q, size_t n_vec, uint8_t *out, size_t out_cap, uint32_t *out_off);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

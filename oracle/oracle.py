@@ -92,6 +92,7 @@ def lib():
         L.flo_o_last_error.restype = C.c_char_p
         L.flo_o_info_read.restype = C.c_int
         L.flo_o_info_read.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Info)]
+        L.flo_o_synth_fill.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint32, C.c_uint64]
         _LIB = L
     return _LIB
 
@@ -279,3 +280,10 @@ def info(flo: bytes) -> Info:
     if lib().flo_o_info_read(bytes(flo), len(flo), C.byref(i)) != 0:
         raise RuntimeError(lib().flo_o_last_error().decode())
     return i
+
+
+def synth_clip(n_sample_frames, channels, seed=0xF10A0D10, clip_id=0):
+    """Host instance of include/flo_synth.h — bit-identical to the device generator."""
+    out = np.zeros(n_sample_frames * channels, np.float32)
+    lib().flo_o_synth_fill(out.ctypes.data, n_sample_frames, channels, seed, clip_id)
+    return out

@@ -1,0 +1,55 @@
+import numpy as np
+import pytest
+
+import flofile
+from fixtures_util import dequantise
+from oracle import oracle as O
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    import flo_amd
+    c = flo_amd.Context(0)
+    yield c
+    c.close()
+
+
+def compare_lossy_stage(g, o, sr, tag=""):
+    """SURVEY §8c tolerances (i)-(iv) for device-vs-oracle on identical input. g/o: dicts with coeffs,q,sf_words."""
+    co, cg = o["coeffs"].astype(np.float64), g["coeffs"].astype(np.float64)
+    rel = np.sqrt(((cg - co) ** 2).sum() / max((co ** 2).sum(), 1e-30))
+    assert rel <= 1e-5, (tag, "coefficient relative RMS", rel)
+    qo, qg = o["q"].astype(np.int32), g["q"].astype(np.int32)
+    flips = int(((qo != 0) != (qg != 0)).sum())
+    assert flips <= 5e-4 * qo.size, (tag, "keep/drop flips", flips, qo.size)
+    both = (qo != 0) & (qg != 0)
+    if both.any():
+        d = np.abs(qo[both] - qg[both])
+        assert d.max() <= 1 and (d != 0).mean() <= 0.01, (tag, "kept mismatches", d.max(), (d != 0).mean())
+    sw = np.abs(o["sf_words"].astype(np.int32) - g["sf_words"].astype(np.int32))
+    assert sw.max() <= 1, (tag, "scale words", sw.max())
+    band = O.psy_tables(sr)[1]
+    do, dg = dequantise(qo, o["sf_words"], band), dequantise(qg, g["sf_words"], band)
+    den = np.sqrt((do ** 2).mean())
+    if den > 0:
+        db = 20 * np.log10(max(np.sqrt(((do - dg) ** 2).mean()), 1e-30) / den)
+        assert db <= -80.0, (tag, "spectral RMS dB", db)
+    return dict(rel=rel, flips=flips)
+
+
+def same_structure(a: bytes, b: bytes):
+    fa, fb = flofile.parse(a), flofile.parse(b)
+    assert fa.crc_valid and fb.crc_valid
+    for k in ("version", "flags", "sample_rate", "channels", "bit_depth", "total_samples", "level", "toc_size", "meta"):
+        assert getattr(fa, k) == getattr(fb, k), k
+    assert len(fa.frames) == len(fb.frames)
+    assert [(f.frame_type, f.frame_samples, f.flags) for f in fa.frames] == [(f.frame_type, f.frame_samples, f.flags) for f in fb.frames]
+    assert [t[3] for t in fa.toc] == [t[3] for t in fb.toc]
+    return fa, fb
+
+
+def snr_db(ref, x):
+    ref, x = ref.astype(np.float64), x.astype(np.float64)
+    n = min(ref.size, x.size)
+    noise = ((ref[:n] - x[:n]) ** 2).sum()
+    return 10 * np.log10(max((ref[:n] ** 2).sum(), 1e-30) / max(noise, 1e-30))
