@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s of lossy quality=high (0.55) encode of synthetic 44.1 kHz stereo.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one pass of the encode hot path over the rank's batch of clips with the PCM already resident in HBM
+and the bitstreams left in HBM; for N > 1 the step ends with the RCCL gather of the packed bitstreams to rank 0.
+Workload (config.workload): every rank holds 1250 synthetic 10-second stereo clips — BASELINE.json's
+"10 000-clip corpus sharded across 8 GPUs" at its per-GPU share, the same at every N (weak scaling). The
+single 3-minute clip of configs[1] is timed in the same run and reported under "single_clip_180s": it is 63 MB
+of PCM, lives in the Infinity Cache and lasts tens of microseconds, so it cannot carry an HBM-roofline claim.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_SAMPLE = 4.0 + 2.0 + 50.0 / 1024.0   # f32 in + i16 out + 25 u16 scale words per 1024
+HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips-per-gpu", type=int, default=1250)
+    ap.add_argument("--clip-seconds", type=float, default=10.0)
+    ap.add_argument("--quality", type=float, default=0.55)
+    ap.add_argument("--path", type=int, default=1, help="1 chain kernel, 2 frame-parallel kernels, 0 auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-clip", action="store_true")
+    ap.add_argument("--cpu-clips", type=int, default=200)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import flo_amd
+
+    sr, ch = 44100, 2
+    n_sf = int(round(args.clip_seconds * sr))
+    n_il = n_sf * ch
+    ctx = flo_amd.Context(local_rank)
+    batch = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [n_il] * args.clips_per_gpu, sr, ch, args.quality)
+    batch.fill_synthetic(seed=0xF10A0D10, clip_id0=rank * args.clips_per_gpu)
+    samples_per_step_rank = n_il * args.clips_per_gpu
+
+    gather = None
+    if world > 1:
+        from flo_amd.dist import BitstreamGather
+        gather = BitstreamGather(ctx, batch, dist, rank, world, local_rank)
+
+    def step():
+        batch.encode(args.path)
+        batch.sync()
+        if gather is not None:
+            gather.run()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kname = "lossy_chain" if args.path in (0, 1) else "lossy_frames"
+    k_ms, k_n = ctx.profile_query(kname)
+    data_bytes = batch.data_bytes()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    total_samples = samples_per_step_rank * world * args.steps
+    value = total_samples / dt / 1e6
+    out = {
+        "metric": "Msamples/s encoded (44.1k stereo, q=high)",
+        "value": round(value, 1),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "realtime_factor": round(value * 1e6 / (sr * ch), 1),
+        "config": {
+            "workload": f"{args.clips_per_gpu} x {args.clip_seconds:g} s 44.1 kHz stereo clips per GPU, lossy quality=high "
+                        f"(0.55): per-GPU shard of BASELINE configs[3] (10 000 clips / 8 GPUs)",
+            "clips_per_gpu": args.clips_per_gpu, "clip_seconds": args.clip_seconds, "quality": args.quality,
+            "kernel_form": {0: "auto", 1: "chain", 2: "frame-parallel"}[args.path],
+            "compressed_bytes_per_gpu": data_bytes,
+        },
+    }
+    if k_n:
+        per_launch_s = k_ms / k_n / 1e3
+        achieved = ALG_BYTES_PER_SAMPLE * samples_per_step_rank / per_launch_s / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel_ms": round(k_ms / k_n, 4), "algorithmic_bytes_per_sample": round(ALG_BYTES_PER_SAMPLE, 4),
+        }
+
+    if not args.no_single_clip and world == 1:
+        n180 = 180 * sr * ch
+        b1 = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [n180], sr, ch, args.quality)
+        b1.fill_synthetic(seed=0xF10A0D10, clip_id0=10_000_000)
+        for _ in range(3):
+            b1.encode(2)
+            b1.sync()
+        reps = 20
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            b1.encode(2)
+        b1.sync()
+        d1 = (time.perf_counter() - t1) / reps
+        out["single_clip_180s"] = {"workload": "BASELINE configs[1]: one 3-min 44.1 kHz stereo clip, q=high, frame-parallel kernels",
+                                   "value": round(n180 / d1 / 1e6, 1), "unit": "Msamples/s", "ms": round(d1 * 1e3, 4),
+                                   "realtime_factor": round(n180 / d1 / (sr * ch), 1)}
+        b1.close()
+
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import oracle as O
+        clips = [O.synth_clip(n_sf, ch, 0xF10A0D10, i) for i in range(args.cpu_clips)]
+        t2 = time.perf_counter()
+        nbytes = 0
+        for c in clips:
+            nbytes += len(O.encode_lossy(c, sr, ch, args.quality))
+        d2 = time.perf_counter() - t2
+        out["cpu_baseline"] = {
+            "value": round(args.cpu_clips * n_il / d2 / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"{args.cpu_clips} of the same synthetic 10 s stereo clips, q=0.55, oracle (C restatement of libflo, "
+                      f"single thread like the reference; the Rust toolchain is not available here), {d2:.1f} s",
+        }
+    print(json.dumps(out))
+    batch.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,21 +84,21 @@ __device__ __forceinline__ void dft8(float *xr, float *xi) {
     float c1r = a5r + a7i, c1i = a5i - a7r;
     float c3r = a5r - a7i, c3i = a5i + a7r;
     // W8^1 c1 = ((c1r + c1i) s, (c1i - c1r) s);  W8^3 c3 = ((c3i - c3r) s, -(c3r + c3i) s);  W8^2 c2 = (c2i, -c2r)
-    float d1r = (c1r + c1i) * s, d1i = (c1i - c1r) * s;
-    float d3r = (c3i - c3r) * s, d3i = -(c3r + c3i) * s;
+    const float e1r = c1r + c1i, e1i = c1i - c1r;
+    const float e3r = c3i - c3r, e3i = c3r + c3i;
     xr[0] = b0r + c0r; xi[0] = b0i + c0i;
     xr[4] = b0r - c0r; xi[4] = b0i - c0i;
-    xr[1] = b1r + d1r; xi[1] = b1i + d1i;
-    xr[5] = b1r - d1r; xi[5] = b1i - d1i;
+    xr[1] = fmaf(e1r, s, b1r); xi[1] = fmaf(e1i, s, b1i);
+    xr[5] = fmaf(-e1r, s, b1r); xi[5] = fmaf(-e1i, s, b1i);
     xr[2] = b2r + c2i; xi[2] = b2i - c2r;
     xr[6] = b2r - c2i; xi[6] = b2i + c2r;
-    xr[3] = b3r + d3r; xi[3] = b3i + d3i;
-    xr[7] = b3r - d3r; xi[7] = b3i - d3i;
+    xr[3] = fmaf(e3r, s, b3r); xi[3] = fmaf(-e3i, s, b3i);
+    xr[7] = fmaf(-e3r, s, b3r); xi[7] = fmaf(e3i, s, b3i);
 }
 
 __device__ __forceinline__ void cmul(float &xr, float &xi, float wr, float wi) {
-    float r = xr * wr - xi * wi;
-    float i = xr * wi + xi * wr;
+    float r = fmaf(xr, wr, -(xi * wi));
+    float i = fmaf(xr, wi, xi * wr);
     xr = r;
     xi = i;
 }
@@ -379,7 +379,7 @@ __device__ __forceinline__ float spread_threshold(float energy, float bcount, co
     const int lane = lane_id();
     const bool is_band = lane < 25;
     float band_db = -100.0f;
-    if (is_band && bcount > 0.f && energy > 1e-10f) band_db = 10.0f * log10f(energy / bcount);
+    if (is_band && bcount > 0.f && energy > 1e-10f) band_db = 10.0f * log10f(__fdiv_rn(energy, bcount));
     if (!is_band) band_db = -__builtin_inff();
     // suffix maximum: bands j >= i mask band i at full strength (spreading[j][i] = 1 for j >= i)
     float sm = band_db;

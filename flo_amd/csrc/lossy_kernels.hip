@@ -46,7 +46,7 @@ __device__ __forceinline__ uint32_t finish_frame(float (&c)[CH][16], LossyLds<CH
         float thr_db = s - 10.0f;
         float tlin = exp10f((T.smr_thr + thr_db) * 0.05f);
         // scale factor (encoder.rs:121-127)
-        float sf = bmax[ch] > 1e-10f ? 30000.0f / bmax[ch] : 1.0f;
+        float sf = bmax[ch] > 1e-10f ? __fdiv_rn(30000.0f, bmax[ch]) : 1.0f;  // IEEE division, as the reference
         sfw[ch] = sf_word(sf);
         if (lane < 25) lds.bandv[ch][lane] = make_float4(tlin, sf, s, 0.f);
     }
