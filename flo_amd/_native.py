@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libflo_hip.so")
+_SO = os.environ.get("FLO_HIP_LIB") or os.path.join(_HERE, "libflo_hip.so")   # FLO_HIP_LIB: diagnostic builds
 _LIB = None
 
 OK = 0

@@ -263,6 +263,7 @@ struct flo_batch {
     short *d_dbg_q = nullptr;
     unsigned short *d_dbg_sfw = nullptr;
     const float *d_in_coeffs = nullptr;
+    int exact = 0;
     // results (host, valid after sync)
     bool encoded = false, synced = false;
     std::vector<uint64_t> h_clip_bytes;
@@ -442,6 +443,7 @@ static LossyArgs make_args(flo_batch *b) {
     A.dbg_q = b->d_dbg_q;
     A.dbg_sfw = b->d_dbg_sfw;
     A.in_coeffs = b->d_in_coeffs;
+    A.exact = b->exact;
     return A;
 }
 
@@ -648,6 +650,7 @@ static int analyze_common(flo_ctx *c, const float *pcm, size_t n, const float *i
         if (hipMemcpy(d_in, in_coeffs, per * 1024 * 4, hipMemcpyHostToDevice) != hipSuccess)
             return done(fail(c, FLO_ERR_DEVICE, "hipMemcpy"));
         b->d_in_coeffs = d_in;
+        b->exact = 1;
     } else {
         rc = flo_batch_upload(b, 0, pcm);
         if (rc != FLO_OK) return done(rc);

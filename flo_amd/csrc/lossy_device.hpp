@@ -49,19 +49,29 @@ constexpr int kCoefFloats = 1280;        // 1024 coefficients, 4 floats of paddi
 constexpr int kSlotCap = 96;
 constexpr int kFrameCap = 4352;          // >= 16 + 6+4+2+100+2*(4+2064), multiple of 16
 
-// per-wave LDS
+// LDS owned by ONE wavefront (CH = channels it processes in lock-step). The three big arrays are live at
+// different times of a frame and share storage.
 template <int CH>
-struct LossyLds {
+struct WaveLds {
     union {
         float xch[CH][kXchFloats];     // FFT exchanges (float2 pairs)
         float coef[CH][kCoefFloats];   // transposition to the contiguous layout
-        uint8_t stage[kFrameCap + 64]; // assembled frame bytes (+ carried tail)
+        int16_t qbuf[CH][1024];        // quantised values, fetched by run-time position while emitting
     } u;
     float2 slots[CH][kSlotCap];        // (sum c^2, max |c|) per lane segment
-    float4 bandv[CH][32];              // per band: (amplitude threshold, scale factor, s dB, unused)
+    float2 bandv[CH][32];              // per band: (amplitude threshold, scale factor)
+    float band_s[CH][32];              // per band: masking level s in dB (exact re-check only)
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// Ordering point between LDS accesses of ONE wavefront (lanes exchange data through LDS). The hardware executes a
+// wave's LDS instructions in order, so no s_barrier is needed; this only pins the compiler.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ------------------------------------------------------------------------------------------------ DFT-8
 // forward (e^{-2 pi i nk/8}), natural order in and out
@@ -133,7 +143,7 @@ __device__ __forceinline__ void fft512(float (&zr)[CH][8], float (&zi)[CH][8], f
 #pragma unroll
             for (int ka = 0; ka < 8; ka++) x[(8 * ka + nc) * kXchStride + nb] = make_float2(zr[c][ka], zi[c][ka]);
         }
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const float2 *x = reinterpret_cast<const float2 *>(xch[c]);
@@ -144,7 +154,7 @@ __device__ __forceinline__ void fft512(float (&zr)[CH][8], float (&zi)[CH][8], f
                 zi[c][r] = v.y;
             }
         }
-        __syncthreads();
+        wave_sync();
     }
     // pass 2 (lane = 8 ka + nc, register = nb)
 #pragma unroll
@@ -166,7 +176,7 @@ __device__ __forceinline__ void fft512(float (&zr)[CH][8], float (&zi)[CH][8], f
 #pragma unroll
             for (int kb = 0; kb < 8; kb++) x[(ka + 8 * kb) * kXchStride + nc] = make_float2(zr[c][kb], zi[c][kb]);
         }
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const float2 *x = reinterpret_cast<const float2 *>(xch[c]);
@@ -177,7 +187,7 @@ __device__ __forceinline__ void fft512(float (&zr)[CH][8], float (&zi)[CH][8], f
                 zi[c][r] = v.y;
             }
         }
-        __syncthreads();
+        wave_sync();
     }
     // pass 3 (lane = ka + 8 kb, register = nc)
 #pragma unroll
@@ -225,6 +235,31 @@ __device__ __forceinline__ void load_half(const float *__restrict__ pcm, long lo
                 he[c][r] = ve ? pcm[se * nch + c0 + c] : 0.f;
                 ho[c][r] = vo ? pcm[so * nch + c0 + c] : 0.f;
             }
+        }
+    }
+}
+
+// Same, when every one of the 1024 sample-frames starting at s0 exists (all but the clip's last frame or two): no
+// per-lane predicates, the 16 loads issue back to back.
+template <int CH>
+__device__ __forceinline__ void load_half_fast(const float *__restrict__ pcm, int nch, int c0, long long s0,
+                                               float (&he)[CH][8], float (&ho)[CH][8]) {
+    const int lane = lane_id();
+    const float *base = pcm + s0 * nch + c0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int eo, oo;
+        half_offsets(lane, r, eo, oo);
+        if (CH == 2) {
+            float2 a = *reinterpret_cast<const float2 *>(base + 2 * eo);
+            float2 b = *reinterpret_cast<const float2 *>(base + 2 * oo);
+            he[0][r] = a.x;
+            he[CH - 1][r] = a.y;
+            ho[0][r] = b.x;
+            ho[CH - 1][r] = b.y;
+        } else {
+            he[0][r] = base[eo * nch];
+            ho[0][r] = base[oo * nch];
         }
     }
 }
@@ -282,7 +317,7 @@ __device__ __forceinline__ void post_rotate_transpose(const float (&zr)[CH][8], 
             coef[ch][p1] = I;
         }
     }
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
         const float4 *p = reinterpret_cast<const float4 *>(&coef[ch][20 * lane]);
@@ -295,18 +330,19 @@ __device__ __forceinline__ void post_rotate_transpose(const float (&zr)[CH][8], 
             c[ch][4 * q + 3] = v.w;
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // ------------------------------------------------------------------------------------------------ bands
-// Per-lane constants of the contiguous layout
+// Per-lane constants of the contiguous layout (lane j owns coefficients 16 j .. 16 j + 15)
 struct LaneConst {
-    uint32_t bnd;      // bit e: segment ends after element e
+    uint32_t bnd;      // bit e: a band segment ends after element e
     uint32_t slot0;    // first slot of this lane
-    uint32_t boff[8];  // 16 x u16: byte offset (band * 16) into bandv for element e
-    float bcount;      // lanes 0..24: bins in band `lane`
-    uint32_t bs0, bs1; // lanes 0..24: slot range of band `lane`
+    uint32_t boff[8];  // 16 x u16: byte offset (band * 8) into bandv for element e
+    float rcount;      // band lanes: 1 / bins in the band (0 for an empty band)
+    uint32_t bs0, bs1; // band lanes: slots [bs0, bs1) with stride 2 belong to this lane
 };
+// Band b is reduced by lane b (even slots of the band) and lane 32 + b (odd slots); lane b adds the two halves.
 
 __device__ __forceinline__ void load_lane_const(LaneConst &L, const LossyDevTables &T) {
     const int lane = lane_id();
@@ -315,18 +351,20 @@ __device__ __forceinline__ void load_lane_const(LaneConst &L, const LossyDevTabl
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         uint32_t b0 = T.band[16 * lane + 2 * i], b1 = T.band[16 * lane + 2 * i + 1];
-        L.boff[i] = (b0 * 16u) | ((b1 * 16u) << 16);
+        L.boff[i] = (b0 * 8u) | ((b1 * 8u) << 16);
     }
-    const int b = lane < 25 ? lane : 24;
-    L.bcount = T.band_count[b];
-    L.bs0 = T.band_slot0[b];
-    L.bs1 = T.band_slot0[b + 1];
+    const int bl = lane & 31;
+    const int b = bl < 25 ? bl : 24;
+    const float cnt = T.band_count[b];
+    L.rcount = cnt > 0.f ? 1.0f / cnt : 0.f;
+    L.bs0 = T.band_slot0[b] + (lane >> 5);
+    L.bs1 = bl < 25 ? T.band_slot0[b + 1] : 0u;
 }
 
 // Band energy (sum of c^2) and band maximum |c| (psychoacoustic.rs:155-163, encoder.rs:111-118).
-// Each lane accumulates its 16 coefficients in ascending order and closes a partial at every band boundary
-// into its own LDS slot; lane b < 25 then adds the slots of band b in ascending order: a fixed summation
-// tree, independent of run and of grid shape. Returns (energy, max) of band `lane` in lanes 0..24.
+// Each lane accumulates its 16 coefficients in ascending order and closes a partial at every band boundary into
+// its own LDS slot; lanes b and 32+b add the even / odd slots of band b in ascending order and lane b adds the two
+// halves: a fixed summation tree, independent of run and of grid shape. Result in lanes 0..24.
 template <int CH>
 __device__ __forceinline__ void band_stats(const float (&c)[CH][16], float2 (*slots)[kSlotCap], const LaneConst &L,
                                            int max_band_slots, float (&energy)[CH], float (&bmax)[CH]) {
@@ -354,14 +392,15 @@ __device__ __forceinline__ void band_stats(const float (&c)[CH][16], float2 (*sl
             slot++;
         }
     }
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
         energy[ch] = 0.f;
         bmax[ch] = 0.f;
     }
-    for (int i = 0; i < max_band_slots; i++) {
-        uint32_t s = L.bs0 + i;
+    const int iters = (max_band_slots + 1) >> 1;
+    for (int i = 0; i < iters; i++) {
+        const uint32_t s = L.bs0 + 2u * (uint32_t)i;
         if (s < L.bs1) {
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
@@ -371,15 +410,22 @@ __device__ __forceinline__ void band_stats(const float (&c)[CH][16], float2 (*sl
             }
         }
     }
-    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+        energy[ch] += __shfl_down(energy[ch], 32);
+        bmax[ch] = fmaxf(bmax[ch], __shfl_down(bmax[ch], 32));
+    }
+    wave_sync();
 }
 
 // Spreading + masking offset (psychoacoustic.rs:166-194): lanes 0..24 in, a[band] out (before temporal masking).
-__device__ __forceinline__ float spread_threshold(float energy, float bcount, const LossyDevTables &T) {
+// 10 log10(e / n) is evaluated as (10 log10 2) * log2(e * (1/n)) with the hardware log2 (1 ulp): the thresholds it
+// feeds are compared at the 1e-6 level by both implementations.
+__device__ __forceinline__ float spread_threshold(float energy, float rcount, const LossyDevTables &T) {
     const int lane = lane_id();
     const bool is_band = lane < 25;
     float band_db = -100.0f;
-    if (is_band && bcount > 0.f && energy > 1e-10f) band_db = 10.0f * log10f(__fdiv_rn(energy, bcount));
+    if (is_band && rcount > 0.f && energy > 1e-10f) band_db = 3.01029995663981195f * __builtin_amdgcn_logf(energy * rcount);
     if (!is_band) band_db = -__builtin_inff();
     // suffix maximum: bands j >= i mask band i at full strength (spreading[j][i] = 1 for j >= i)
     float sm = band_db;
@@ -405,6 +451,12 @@ __device__ __forceinline__ float spread_threshold(float energy, float bcount, co
     return m + (-6.0f);
 }
 
+// amplitude-domain threshold of a masking level s (dB): 10^((smr_thr + fl(s - 10)) / 20), hardware exp2
+__device__ __forceinline__ float masking_amplitude(float s, float smr_thr) {
+    const float thr_db = s - 10.0f;
+    return __builtin_amdgcn_exp2f((smr_thr + thr_db) * 0.16609640474436813f);  // log2(10) / 20
+}
+
 // scale-factor word (encoder.rs:262-266)
 __device__ __forceinline__ uint32_t sf_word(float sf) {
     if (sf > 1e-10f) {
@@ -424,12 +476,13 @@ __device__ __forceinline__ float round_away(float x) {
 
 // ------------------------------------------------------------------------------------------------ quantise
 // Keep/drop + quantise 16 contiguous coefficients per channel (psychoacoustic.rs:205-234, encoder.rs:138-151).
-// bandv[band] = (amplitude threshold from the masking level, scale factor, masking level s in dB, -).
-// The keep test |c| > max(T_band, T_ath) is the reference's dB-domain test 20 log10|c| - (max(s, ath) - 10) > thr
-// moved to the amplitude domain; coefficients within 1e-5 (relative) of the threshold are re-decided with the
-// reference's exact f32 expression so that rounding of the reformulation never decides.
-template <int CH>
-__device__ __forceinline__ void quantise(const float (&c)[CH][16], const float4 (*bandv)[32], const LaneConst &L,
+// bandv[band] = (amplitude threshold from the masking level, scale factor). The keep test |c| > max(T_band, T_ath)
+// is the reference's dB-domain test 20 log10|c| - (max(s, ath) - 10) > thr moved to the amplitude domain (both
+// carry f32 rounding of a few 1e-7 relative). With EXACT, coefficients within 1e-5 (relative) of the
+// threshold are re-decided with the reference's own f32 expression (used by the stage tests).
+// No clamp is needed after rounding: |c * 30000/band_max| <= 30000 (1 + 2^-23), and band_max <= 1e-10 gives sf = 1.
+template <int CH, bool EXACT>
+__device__ __forceinline__ void quantise(const float (&c)[CH][16], const WaveLds<CH> &lds, const LaneConst &L,
                                          const LossyDevTables &T, int (&q)[CH][16]) {
     const int lane = lane_id();
     float al[16];
@@ -446,26 +499,23 @@ __device__ __forceinline__ void quantise(const float (&c)[CH][16], const float4 
         const uint32_t off = (e & 1) ? (L.boff[e >> 1] >> 16) : (L.boff[e >> 1] & 0xFFFFu);
 #pragma unroll
         for (int ch = 0; ch < CH; ch++) {
-            const float4 bv = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(bandv[ch]) + off);
+            const float2 bv = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lds.bandv[ch]) + off);
             const float x = c[ch][e];
             const float ax = fabsf(x);
             const float thr = fmaxf(bv.x, al[e]);
             bool keep = ax > thr;
-            // |c| <= 1e-10 takes the reference's "-100 dB" branch; it can only be kept at quality >= 0.99
-            const bool near = fabsf(ax - thr) <= 1e-5f * thr || (T.q_transparent && !(ax > 1e-10f));
-            if (near) {
-                // exact reference expression
-                float signal_db = ax > 1e-10f ? 20.0f * log10f(ax) : -100.0f;
-                float t = fmaxf(bv.z, T.ath_db[16 * lane + e]) - 10.0f;
-                keep = (signal_db - t) > T.smr_thr;
+            if (EXACT) {
+                // |c| <= 1e-10 takes the reference's "-100 dB" branch; it can only be kept at quality >= 0.99
+                const bool near = fabsf(ax - thr) <= 1e-5f * thr || (T.q_transparent && !(ax > 1e-10f));
+                if (near) {
+                    float signal_db = ax > 1e-10f ? 20.0f * log10f(ax) : -100.0f;
+                    float sdb = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds.band_s[ch]) + (off >> 1));
+                    float t = fmaxf(sdb, T.ath_db[16 * lane + e]) - 10.0f;
+                    keep = (signal_db - t) > T.smr_thr;
+                }
             }
-            int v = 0;
-            if (keep) {
-                float r = round_away(x * bv.y);
-                r = fminf(fmaxf(r, -32768.0f), 32767.0f);
-                v = (int)r;
-            }
-            q[ch][e] = v;
+            const int v = __float2int_rz(round_away(x * bv.y));  // saturating; NaN -> 0
+            q[ch][e] = keep ? v : 0;
         }
     }
 }
@@ -492,27 +542,35 @@ __device__ __forceinline__ int wave_excl_max_up(int v, int ident) {  // max over
     }
     return x;
 }
-__device__ __forceinline__ int wave_excl_min_down(int v, int ident) {  // min over lanes > lane
+// two independent u16 minima over lanes > lane, packed in one register (positions are <= 1024)
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t wave_excl_min2_down(uint32_t packed, uint32_t ident) {
     const int lane = lane_id();
-    int x = __shfl_down(v, 1);
+    uint32_t x = __shfl_down(packed, 1);
     if (lane == 63) x = ident;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_down(x, d);
-        if (lane + d < 64) x = min(x, t);
+        uint32_t t = __shfl_down(x, d);
+        if (lane + d < 64) {
+            ushort2_t a = __builtin_bit_cast(ushort2_t, x), b = __builtin_bit_cast(ushort2_t, t);
+            x = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(a, b));
+        }
     }
     return x;
 }
 
-// Size and per-lane offsets of serialize_sparse (encoder.rs:284-314) for the 1024 values of one channel held
-// 16 per lane. Records: [varint zero_run][u8 n <= 255][n x i16]; a trailing zero run closes with [varint][0].
+// serialize_sparse (encoder.rs:284-314) of the 1024 values of one channel held 16 per lane.
+// Records: [varint zero_run][u8 n <= 255][n x i16]; a trailing zero run closes with [varint][0]; a non-zero run
+// longer than 255 continues with [0][n] records; a walk that starts on a non-zero starts with [0][n].
+// Every value and every record header has a closed-form byte offset:
+//   offset(position p of lane) = off0 + 2 * popcount(M & K_p),  M = non-zero mask | header mask << 16
+// where the header mask marks positions that start a record (zero-run starts, 255-cap continuations, the start
+// record); only the last zero run of a lane can be >= 128 long (3-byte header) and nothing of that lane follows it.
 struct SparsePlan {
-    uint32_t m;        // non-zero mask of this lane's 16 values
-    uint32_t zs;       // zero-run starts in this lane
+    uint32_t M;        // bits 0..15 non-zero mask, bits 16..31 record-start mask
     int nn;            // position of the first non-zero after this lane (1024 if none)
     int nz_end;        // position of the first zero after this lane (1024 if none)
-    int t_in;          // length of the non-zero run ending just before this lane
-    int cc_pos;        // local position of a 255-cap continuation record (or -1)
+    uint32_t cross_cnt;  // count byte of the zero-run record that leaves this lane (if any)
     uint32_t off0;     // byte offset (within the channel's sparse blob) of this lane's first byte
     uint32_t total;    // total sparse bytes (uniform)
 };
@@ -522,90 +580,101 @@ __device__ __forceinline__ void sparse_plan(const int (&q)[16], SparsePlan &P) {
     uint32_t m = 0;
 #pragma unroll
     for (int e = 0; e < 16; e++) m |= (q[e] != 0 ? 1u : 0u) << e;
-    P.m = m;
     const uint32_t prev_m = __shfl_up(m, 1);
     const uint32_t prev_nz = lane == 0 ? 0u : (prev_m >> 15) & 1u;
     uint32_t zs = ~m & ((m << 1) | prev_nz) & 0xFFFFu;
-    if (lane == 0 && !(m & 1u)) zs |= 1u;  // the walk starts with a (possibly empty... no: non-empty) zero run
-    P.zs = zs;
+    if (lane == 0 && !(m & 1u)) zs |= 1u;  // the walk starts with a zero run
     const int base = 16 * lane;
     // look-ahead / look-behind over the other lanes
-    const int first_nz = m ? base + __builtin_ctz(m) : 1024;
     const uint32_t inv = ~m & 0xFFFFu;
-    const int first_z = inv ? base + __builtin_ctz(inv) : 1024;
+    const uint32_t first_nz = m ? (uint32_t)(base + __builtin_ctz(m)) : 1024u;
+    const uint32_t first_z = inv ? (uint32_t)(base + __builtin_ctz(inv)) : 1024u;
     const int last_z = inv ? base + 31 - __builtin_clz(inv) : -1;
-    P.nn = wave_excl_min_down(first_nz, 1024);
-    P.nz_end = wave_excl_min_down(first_z, 1024);
+    const uint32_t nxt = wave_excl_min2_down(first_nz | (first_z << 16), 1024u | (1024u << 16));
+    P.nn = (int)(nxt & 0xFFFFu);
+    P.nz_end = (int)(nxt >> 16);
     const int lz_before = wave_excl_max_up(last_z, -1);
-    P.t_in = base - 1 - lz_before;
+    const int t_in = base - 1 - lz_before;  // length of the non-zero run ending just before this lane
     // 255-cap continuation: a position i in the leading non-zeros with (t_in + i) % 255 == 0 and t_in + i > 0
-    const int ln = inv ? __builtin_ctz(inv) : 16;  // leading non-zeros
-    P.cc_pos = -1;
-    if (P.t_in > 0) {
-        int x = (255 - (P.t_in % 255)) % 255;
-        if (x < ln) P.cc_pos = x;
+    const int ln = inv ? __builtin_ctz(inv) : 16;
+    uint32_t hmask = zs;
+    if (t_in > 0) {
+        int x = (255 - (t_in % 255)) % 255;
+        if (x < ln) hmask |= 1u << x;
     }
-    // header bytes of the records that start in this lane
-    uint32_t hdr = 2u * (uint32_t)__builtin_popcount(zs);
-    if (zs) {
-        // only the last zero run of a lane can leave it; its length decides the varint size
-        int s = 31 - __builtin_clz(zs);
-        uint32_t above = m >> s;  // bit 0 is the zero at s
-        int end = above ? base + s + __builtin_ctz(above) : P.nn;
-        if (end - (base + s) >= 128) hdr += 1u;
+    if (lane == 0 && (m & 1u)) hmask |= 1u;  // record that starts the walk on a non-zero
+    P.M = m | (hmask << 16);
+    // the zero run that leaves this lane (only the last one can): its length decides the varint size, and its count
+    // byte needs the length of the non-zero run that follows in another lane
+    uint32_t bytes = 2u * (uint32_t)__builtin_popcount(P.M);
+    const int s_last = zs ? 31 - __builtin_clz(zs) : 0;
+    const bool crossing = zs && ((m >> s_last) == 0u);
+    const int end = crossing ? P.nn : base;
+    if (crossing && end - (base + s_last) >= 128) bytes += 1u;
+    {
+        const int src = end < 1024 ? (end >> 4) : lane;
+        const uint32_t m2 = __shfl(m, src);
+        const int nzend2 = __shfl(P.nz_end, src);
+        const int e2 = end & 15;
+        const int run2 = __builtin_ctz(~(m2 >> e2));
+        const int len = (e2 + run2 >= 16) ? nzend2 - end : run2;
+        P.cross_cnt = end >= 1024 ? 0u : (uint32_t)(len < 255 ? len : 255);
     }
-    if (P.cc_pos >= 0) hdr += 2u;
-    if (lane == 0 && (m & 1u)) hdr += 2u;  // record that starts the walk on a non-zero
-    const uint32_t bytes = hdr + 2u * (uint32_t)__builtin_popcount(m);
     const uint32_t incl = wave_incl_sum(bytes);
     P.off0 = incl - bytes;
     P.total = __shfl(incl, 63);
 }
 
-// Emit this lane's part of the sparse blob to `dst` (LDS bytes; the blob starts at dst[0]). Values are fetched by
-// run-time position from qv (this lane's 16 values parked in LDS) so no register array is indexed dynamically.
-// A zero-run record reserves its count byte; the first non-zero of the following run fills it in.
-__device__ __forceinline__ void sparse_emit(const int16_t *qv, const SparsePlan &P, uint8_t *dst) {
+// Emit this lane's part of the sparse blob to `dst` (LDS bytes; the blob starts at dst[0]). qv = this lane's 16
+// values parked in LDS (the header loop fetches nothing from it; the value loop is static).
+__device__ __forceinline__ void sparse_emit(const int (&q)[16], const SparsePlan &P, uint8_t *dst) {
     const int lane = lane_id();
     const int base = 16 * lane;
-    uint32_t off = P.off0;
-    uint32_t ev = P.zs | P.m;
-    const uint32_t prev_nz_bit = (P.t_in > 0) ? 1u : 0u;
-    while (ev) {
-        const int i = __builtin_ctz(ev);
-        ev &= ev - 1;
-        if ((P.zs >> i) & 1u) {
-            const uint32_t above = P.m >> i;
-            const int end = above ? base + i + __builtin_ctz(above) : P.nn;
-            const uint32_t zc = (uint32_t)(end - (base + i));
-            if (zc >= 128u) {
-                dst[off] = (uint8_t)((zc & 0x7Fu) | 0x80u);
-                dst[off + 1] = (uint8_t)(zc >> 7);
-                off += 2;
-            } else {
-                dst[off] = (uint8_t)zc;
-                off += 1;
-            }
-            if (end >= 1024) dst[off] = 0;  // trailing zeros: [varint][0]
-            off += 1;
+    const uint32_t m = P.M & 0xFFFFu;
+    // record headers
+    uint32_t hm = P.M >> 16;
+    while (hm) {
+        const int s = __builtin_ctz(hm);
+        hm &= hm - 1;
+        const uint32_t below = (1u << s) - 1u;
+        uint32_t off = P.off0 + 2u * (uint32_t)__builtin_popcount(P.M & (below | (below << 16)));
+        const uint32_t above = m >> s;  // bit 0 = position s
+        uint32_t zc = 0, cnt;
+        int e;  // local position where the record's non-zero run starts
+        if (above & 1u) {
+            e = s;  // continuation / start record: [0][n]
+        } else if (above) {
+            e = s + __builtin_ctz(above);
+            zc = (uint32_t)(e - s);
         } else {
-            const bool prev_is_nz = i > 0 ? ((P.m >> (i - 1)) & 1u) : prev_nz_bit;
-            const uint32_t rest = P.m >> i;
-            const int run_local = __builtin_ctz(~rest);
-            const int run_end = (i + run_local >= 16) ? P.nz_end : base + i + run_local;
-            const uint32_t remaining = (uint32_t)(run_end - (base + i));
-            const uint8_t cnt = (uint8_t)(remaining < 255u ? remaining : 255u);
-            if (i == P.cc_pos || (lane == 0 && i == 0)) {
-                dst[off] = 0;
-                dst[off + 1] = cnt;
-                off += 2;
-            } else if (!prev_is_nz) {
-                dst[off - 1] = cnt;
-            }
-            const uint32_t v = (uint16_t)qv[i];
+            e = 16;  // the zero run leaves the lane
+            zc = (uint32_t)(P.nn - (base + s));
+        }
+        if (e < 16) {
+            const int run = __builtin_ctz(~(m >> e));
+            const int len = (e + run >= 16) ? P.nz_end - (base + e) : run;
+            cnt = (uint32_t)(len < 255 ? len : 255);
+        } else {
+            cnt = P.cross_cnt;
+        }
+        if (zc >= 128u) {
+            dst[off] = (uint8_t)((zc & 0x7Fu) | 0x80u);
+            dst[off + 1] = (uint8_t)(zc >> 7);
+            dst[off + 2] = (uint8_t)cnt;
+        } else {
+            dst[off] = (uint8_t)zc;
+            dst[off + 1] = (uint8_t)cnt;
+        }
+    }
+    // values
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t K = ((1u << i) - 1u) | (((2u << i) - 1u) << 16);
+        if ((m >> i) & 1u) {
+            const uint32_t off = P.off0 + 2u * (uint32_t)__builtin_popcount(P.M & K);
+            const uint32_t v = (uint32_t)q[i];
             dst[off] = (uint8_t)v;
             dst[off + 1] = (uint8_t)(v >> 8);
-            off += 2;
         }
     }
 }

@@ -20,113 +20,99 @@ struct FrameState {
     float prev[CH];  // lanes 0..24: temporal masking state of band `lane`
 };
 
-// Everything after the MDCT for one frame of CH channels. c = coefficients (contiguous layout).
-// Returns the frame length in bytes; the frame is assembled in lds.u.stage at byte offset `pend`.
-template <int CH, bool BANDS_ONLY>
-__device__ __forceinline__ uint32_t finish_frame(float (&c)[CH][16], LossyLds<CH> &lds, const LaneConst &L,
-                                                 const LossyArgs &A, FrameState<CH> &st, uint32_t pend,
-                                                 uint32_t tailbyte, unsigned long long gframe, int16_t *qbuf) {
+// Everything between the MDCT and the byte stream for CH channels held by this wave: band statistics, masking
+// level, temporal masking, scale factors, quantiser, sparse-RLE plan. ch0 = index of c[0] among the clip's channels.
+template <int CH, bool BANDS_ONLY, bool EXACT>
+__device__ __forceinline__ void analyse_frame(float (&c)[CH][16], WaveLds<CH> &lds, const LaneConst &L,
+                                              const LossyArgs &A, int ch0, FrameState<CH> &st,
+                                              unsigned long long gframe, int (&q)[CH][16], uint32_t (&sfw)[CH],
+                                              SparsePlan (&P)[CH]) {
     const int lane = lane_id();
     const LossyDevTables &T = A.T;
     float energy[CH], bmax[CH];
     band_stats<CH>(c, lds.slots, L, T.max_band_slots, energy, bmax);
-
-    uint32_t sfw[CH];
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
-        float a = spread_threshold(energy[ch], L.bcount, T);
+        float a = spread_threshold(energy[ch], L.rcount, T);
         if (BANDS_ONLY) {
-            if (lane < 25) A.a_t[(gframe * A.nch + ch) * 32 + lane] = a;
+            if (lane < 25) A.a_t[(gframe * A.nch + ch0 + ch) * 32 + lane] = a;
             continue;
         }
         // temporal masking (psychoacoustic.rs:196-203)
         float s = fmaxf(a, st.prev[ch] * 0.7f);
         st.prev[ch] = s;
-        // amplitude-domain threshold of the masking level: 10^((smr_thr + fl(s - 10)) / 20)
-        float thr_db = s - 10.0f;
-        float tlin = exp10f((T.smr_thr + thr_db) * 0.05f);
-        // scale factor (encoder.rs:121-127)
-        float sf = bmax[ch] > 1e-10f ? __fdiv_rn(30000.0f, bmax[ch]) : 1.0f;  // IEEE division, as the reference
+        const float tlin = masking_amplitude(s, T.smr_thr);
+        // scale factor (encoder.rs:121-127): IEEE division, as the reference
+        const float sf = bmax[ch] > 1e-10f ? __fdiv_rn(30000.0f, bmax[ch]) : 1.0f;
         sfw[ch] = sf_word(sf);
-        if (lane < 25) lds.bandv[ch][lane] = make_float4(tlin, sf, s, 0.f);
+        if (lane < 25) {
+            lds.bandv[ch][lane] = make_float2(tlin, sf);
+            if (EXACT) lds.band_s[ch][lane] = s;
+        }
     }
-    if (BANDS_ONLY) return 0;
-    __syncthreads();
-
-    int q[CH][16];
-    quantise<CH>(c, lds.bandv, L, T, q);
-
-    // dense outputs for the analysis entry points
+    if (BANDS_ONLY) return;
+    wave_sync();
+    quantise<CH, EXACT>(c, lds, L, T, q);
     if (A.dbg_q) {
 #pragma unroll
         for (int ch = 0; ch < CH; ch++) {
-            short *dq = A.dbg_q + (gframe * A.nch + ch) * 1024 + 16 * lane;
+            short *dq = A.dbg_q + (gframe * A.nch + ch0 + ch) * 1024 + 16 * lane;
 #pragma unroll
             for (int e = 0; e < 16; e++) dq[e] = (short)q[ch][e];
         }
     }
     if (A.dbg_sfw && lane < 25) {
 #pragma unroll
-        for (int ch = 0; ch < CH; ch++) A.dbg_sfw[(gframe * A.nch + ch) * 25 + lane] = (unsigned short)sfw[ch];
+        for (int ch = 0; ch < CH; ch++) A.dbg_sfw[(gframe * A.nch + ch0 + ch) * 25 + lane] = (unsigned short)sfw[ch];
     }
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) sparse_plan(q[ch], P[ch]);
+}
 
-    SparsePlan P[CH];
-#pragma unroll
-    for (int ch = 0; ch < CH; ch++) {
-        sparse_plan(q[ch], P[ch]);
-        // values are fetched by run-time position while emitting: park them in LDS
-        uint32_t *qb = reinterpret_cast<uint32_t *>(qbuf + ch * 1024 + 16 * lane);
-#pragma unroll
-        for (int e = 0; e < 8; e++) qb[e] = ((uint32_t)q[ch][2 * e] & 0xFFFFu) | ((uint32_t)q[ch][2 * e + 1] << 16);
+// Write this wave's share of the frame bytes (writer.rs:236-254 + encoder.rs:243-280) into the staging buffer.
+// tot[c] = sparse bytes of channel c for ALL nch channels of the frame (uniform); the wave that holds channel 0
+// also writes the frame and blob headers. Returns the frame length.
+template <int CH>
+__device__ __forceinline__ uint32_t emit_frame(uint8_t *f, int nch, int ch0, const uint32_t *tot,
+                                               const uint32_t (&sfw)[CH], const SparsePlan (&P)[CH],
+                                               const int (&q)[CH][16]) {
+    const int lane = lane_id();
+    uint32_t pos = 12 + 50 * (uint32_t)nch;
+    uint32_t chpos[2];
+    for (int c = 0; c < nch; c++) {
+        chpos[c] = pos;
+        pos += 4 + tot[c];
     }
-    __syncthreads();
-
-    // ---- assemble the frame bytes (writer.rs:236-254 + encoder.rs:243-280) in LDS ----
-    uint8_t *stg = lds.u.stage;
-    if (lane < (int)pend) stg[lane] = (uint8_t)tailbyte;
-    uint8_t *f = stg + pend;
-    uint32_t pos = 12 + 50 * CH;  // first sparse length field
-    uint32_t chpos[CH];
-#pragma unroll
-    for (int ch = 0; ch < CH; ch++) {
-        chpos[ch] = pos;
-        pos += 4 + P[ch].total;
-    }
-    const uint32_t flen = pos;
-    const uint32_t blob_len = flen - 10;
-    if (lane == 0) {
+    const uint32_t flen = pos, blob_len = flen - 10;
+    if (ch0 == 0 && lane == 0) {
         f[0] = 253;
         f[1] = 0x00; f[2] = 0x04; f[3] = 0; f[4] = 0;  // frame_samples = 1024
         f[5] = 0;
         f[6] = (uint8_t)blob_len; f[7] = (uint8_t)(blob_len >> 8); f[8] = (uint8_t)(blob_len >> 16); f[9] = (uint8_t)(blob_len >> 24);
         f[10] = 0;  // BlockSize::Long
-        f[11] = (uint8_t)CH;
-#pragma unroll
-        for (int ch = 0; ch < CH; ch++) {
-            uint32_t l = P[ch].total;
-            uint8_t *p = f + chpos[ch];
-            p[0] = (uint8_t)l; p[1] = (uint8_t)(l >> 8); p[2] = (uint8_t)(l >> 16); p[3] = (uint8_t)(l >> 24);
-        }
-    }
-    if (lane < 25) {
-#pragma unroll
-        for (int ch = 0; ch < CH; ch++) {
-            f[12 + 50 * ch + 2 * lane] = (uint8_t)sfw[ch];
-            f[12 + 50 * ch + 2 * lane + 1] = (uint8_t)(sfw[ch] >> 8);
-        }
+        f[11] = (uint8_t)nch;
     }
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
-        sparse_emit(qbuf + ch * 1024 + 16 * lane, P[ch], f + chpos[ch] + 4);
+        const int c = ch0 + ch;
+        if (lane < 25) {
+            f[12 + 50 * c + 2 * lane] = (uint8_t)sfw[ch];
+            f[12 + 50 * c + 2 * lane + 1] = (uint8_t)(sfw[ch] >> 8);
+        }
+        if (lane == 32) {
+            const uint32_t l = tot[c];
+            uint8_t *p = f + chpos[c];
+            p[0] = (uint8_t)l; p[1] = (uint8_t)(l >> 8); p[2] = (uint8_t)(l >> 16); p[3] = (uint8_t)(l >> 24);
+        }
+        sparse_emit(q[ch], P[ch], f + chpos[c] + 4);
     }
-    __syncthreads();
     return flen;
 }
 
 // MDCT of one frame of CH channels: halves (ae,ao) + (be,bo) -> c (contiguous layout)
 template <int CH>
 __device__ __forceinline__ void mdct_frame(const float (&ae)[CH][8], const float (&ao)[CH][8],
-                                           const float (&be)[CH][8], const float (&bo)[CH][8], LossyLds<CH> &lds,
+                                           const float (&be)[CH][8], const float (&bo)[CH][8], WaveLds<CH> &lds,
                                            const LossyDevTables &T, float (&c)[CH][16]) {
     float zr[CH][8], zi[CH][8];
     fold<CH>(ae, ao, be, bo, zr, zi, T);
@@ -136,23 +122,23 @@ __device__ __forceinline__ void mdct_frame(const float (&ae)[CH][8], const float
 
 template <int CH>
 __device__ __forceinline__ void store_coeffs_dbg(const float (&c)[CH][16], const LossyArgs &A,
-                                                 unsigned long long gframe) {
+                                                 unsigned long long gframe, int ch0) {
     if (!A.dbg_coeffs) return;
     const int lane = lane_id();
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
-        float4 *d = reinterpret_cast<float4 *>(A.dbg_coeffs + (gframe * A.nch + ch) * 1024 + 16 * lane);
+        float4 *d = reinterpret_cast<float4 *>(A.dbg_coeffs + (gframe * A.nch + ch0 + ch) * 1024 + 16 * lane);
 #pragma unroll
         for (int q = 0; q < 4; q++) d[q] = make_float4(c[ch][4 * q], c[ch][4 * q + 1], c[ch][4 * q + 2], c[ch][4 * q + 3]);
     }
 }
 
 template <int CH>
-__device__ __forceinline__ void load_coeffs(float (&c)[CH][16], const LossyArgs &A, unsigned long long gframe) {
+__device__ __forceinline__ void load_coeffs(float (&c)[CH][16], const LossyArgs &A, unsigned long long gframe, int ch0) {
     const int lane = lane_id();
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
-        const float4 *s = reinterpret_cast<const float4 *>(A.in_coeffs + (gframe * A.nch + ch) * 1024 + 16 * lane);
+        const float4 *s = reinterpret_cast<const float4 *>(A.in_coeffs + (gframe * A.nch + ch0 + ch) * 1024 + 16 * lane);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             float4 v = s[q];
@@ -161,7 +147,6 @@ __device__ __forceinline__ void load_coeffs(float (&c)[CH][16], const LossyArgs 
     }
 }
 
-// ---------------------------------------------------------------------------------------------- chain kernel
 // Add an opaque zero to the table pointers once per frame: the loads then depend on a value the compiler cannot
 // see through, so they stay inside the frame loop (served by L1/L2) instead of being hoisted into ~100 registers.
 // The pointers keep their global address space (laundering the pointer itself degrades them to flat loads).
@@ -173,80 +158,104 @@ __device__ __forceinline__ void launder_tables(LossyDevTables &T) {
     T.s10d += zero;
 }
 
-template <int CH>
-__global__ __launch_bounds__(64) void lossy_chain_kernel(LossyArgs A) {
-    __shared__ LossyLds<CH> lds;
-    __shared__ int16_t qbuf[CH * 1024];
+// ---------------------------------------------------------------------------------------------- chain kernel
+// One workgroup per clip, one wavefront per channel (NW = channels = 1 or 2). Each wave walks its channel's frames
+// in order: raw samples of the overlapping half-frame and the 25-float masking state stay in registers, so every
+// PCM sample is read from HBM once. The waves meet three times per frame to assemble and flush the frame bytes.
+#ifndef FLO_CHAIN_WAVES_PER_SIMD
+#define FLO_CHAIN_WAVES_PER_SIMD 3
+#endif
+template <int NW, bool EXACT>
+__global__ __launch_bounds__(64 * NW, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_kernel(LossyArgs A) {
+    __shared__ WaveLds<1> wl[NW];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64];
+    __shared__ uint32_t tot_sh[2];
     const int lane = lane_id();
+    const int w = NW == 1 ? 0 : (int)(threadIdx.x >> 6);  // channel of this wave
+    const int tid = (int)threadIdx.x;
     const unsigned clip = blockIdx.x;
-    if (clip >= (unsigned)A.n_clips) return;
     const float *pcm = A.pcm + A.clip_off[clip];
     const long long n_sf = (long long)A.clip_nsf[clip];
     const unsigned hops = A.clip_hops[clip];
     const unsigned long long frame0 = A.clip_frame0[clip];
     uint8_t *gout = A.out + A.out_off[clip];
+    WaveLds<1> &lds = wl[w];
 
     LaneConst L;
     load_lane_const(L, A.T);
-    FrameState<CH> st;
-#pragma unroll
-    for (int ch = 0; ch < CH; ch++) st.prev[ch] = 0.f;
+    FrameState<1> st;
+    st.prev[0] = 0.f;
 
-    float ae[CH][8], ao[CH][8], be[CH][8], bo[CH][8];
+    float ae[1][8], ao[1][8], be[1][8], bo[1][8];
 #pragma unroll
-    for (int ch = 0; ch < CH; ch++)
-#pragma unroll
-        for (int r = 0; r < 8; r++) ae[ch][r] = ao[ch][r] = 0.f;  // pre-roll: 1024 zeros (encoder.rs:177)
-    if (!A.in_coeffs) load_half<CH>(pcm, n_sf, A.nch, 0, 0, be, bo);
+    for (int r = 0; r < 8; r++) ae[0][r] = ao[0][r] = 0.f;  // pre-roll: 1024 zeros (encoder.rs:177)
+    if (!A.in_coeffs) {
+        if (n_sf >= 1024) load_half_fast<1>(pcm, NW, w, 0, be, bo);
+        else load_half<1>(pcm, n_sf, NW, w, 0, be, bo);
+    }
 
     unsigned long long written = 0;
-    uint32_t pend = 0, tailbyte = 0;
+    uint32_t pend = 0;
     for (unsigned h = 0; h < hops; h++) {
-        // Keep the constant tables in cache, not in registers: without this the compiler hoists ~100 loop-invariant
-        // table loads out of the frame loop and the kernel drops to one wave per SIMD.
         launder_tables(A.T);
-        float c[CH][16];
+        float c[1][16];
         if (A.in_coeffs) {
-            load_coeffs<CH>(c, A, frame0 + h);
+            load_coeffs<1>(c, A, frame0 + h, w);
         } else {
-            float zr[CH][8], zi[CH][8];
-            fold<CH>(ae, ao, be, bo, zr, zi, A.T);
+            float zr[1][8], zi[1][8];
+            fold<1>(ae, ao, be, bo, zr, zi, A.T);
 #pragma unroll
-            for (int ch = 0; ch < CH; ch++)
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    ae[ch][r] = be[ch][r];
-                    ao[ch][r] = bo[ch][r];
-                }
+            for (int r = 0; r < 8; r++) {
+                ae[0][r] = be[0][r];
+                ao[0][r] = bo[0][r];
+            }
             // issue the next half-frame's loads now; they are consumed at the top of the next iteration
-            if (h + 1 < hops) load_half<CH>(pcm, n_sf, A.nch, 0, (long long)(h + 1) * 1024, be, bo);
-            fft512<CH>(zr, zi, lds.u.xch, A.T);
-            post_rotate_transpose<CH>(zr, zi, lds.u.coef, c, A.T);
-            store_coeffs_dbg<CH>(c, A, frame0 + h);
+            if (h + 1 < hops) {
+                const long long s0 = (long long)(h + 1) * 1024;
+                if (s0 + 1024 <= n_sf) load_half_fast<1>(pcm, NW, w, s0, be, bo);
+                else load_half<1>(pcm, n_sf, NW, w, s0, be, bo);
+            }
+            fft512<1>(zr, zi, lds.u.xch, A.T);
+            post_rotate_transpose<1>(zr, zi, lds.u.coef, c, A.T);
+            store_coeffs_dbg<1>(c, A, frame0 + h, w);
         }
-        const uint32_t flen = finish_frame<CH, false>(c, lds, L, A, st, pend, tailbyte, frame0 + h, qbuf);
-        if (lane == 0) A.frame_size[frame0 + h] = flen;
-        // flush complete 16-byte chunks, carry the rest
+        int q[1][16];
+        uint32_t sfw[1];
+        SparsePlan P[1];
+        analyse_frame<1, false, EXACT>(c, lds, L, A, w, st, frame0 + h, q, sfw, P);
+        if (NW > 1) {
+            if (lane == 0) tot_sh[w] = P[0].total;
+            __syncthreads();
+        }
+        uint32_t tot[2];
+        tot[0] = NW > 1 ? tot_sh[0] : P[0].total;
+        tot[1] = NW > 1 ? tot_sh[1] : 0u;
+        const uint32_t flen = emit_frame<1>(stage + pend, NW, w, tot, sfw, P, q);
+        __syncthreads();
+        if (tid == 0) A.frame_size[frame0 + h] = flen;
+        // flush complete 16-byte chunks, carry the rest at the front of the staging buffer
         const uint32_t have = pend + flen;
         const uint32_t n16 = have >> 4;
-        const uint4 *src = reinterpret_cast<const uint4 *>(lds.u.stage);
+        const uint4 *src = reinterpret_cast<const uint4 *>(stage);
         uint4 *dst = reinterpret_cast<uint4 *>(gout + written);
-        for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
+        for (uint32_t i = tid; i < n16; i += 64 * NW) dst[i] = src[i];
         pend = have & 15u;
-        tailbyte = (lane < (int)pend) ? lds.u.stage[(n16 << 4) + lane] : 0u;
+        const uint32_t tb = (tid < (int)pend) ? stage[(n16 << 4) + tid] : 0u;
         written += (unsigned long long)n16 << 4;
         __syncthreads();
+        if (tid < (int)pend) stage[tid] = (uint8_t)tb;
     }
-    if (lane < (int)pend) gout[written + lane] = (uint8_t)tailbyte;
-    if (lane == 0) A.clip_bytes[clip] = written + pend;
+    __syncthreads();
+    if (tid < (int)pend) gout[written + tid] = stage[tid];
+    if (tid == 0) A.clip_bytes[clip] = written + pend;
 }
 
 // ---------------------------------------------------------------------------------------------- frame-parallel
-// PASS 1: a_t only. PASS 2: full frame into slot gframe.
-template <int CH, int PASS>
+// PASS 1: a_t only. PASS 2: full frame into slot gframe. One wave per frame, CH = all channels in lock-step.
+template <int CH, int PASS, bool EXACT>
 __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
-    __shared__ LossyLds<CH> lds;
-    __shared__ int16_t qbuf[CH * 1024];
+    __shared__ WaveLds<CH> lds;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64];
     const int lane = lane_id();
     const unsigned long long gframe = blockIdx.x;
     if (gframe >= A.total_frames) return;
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
     load_lane_const(L, A.T);
     float c[CH][16];
     if (A.in_coeffs) {
-        load_coeffs<CH>(c, A, gframe);
+        load_coeffs<CH>(c, A, gframe, 0);
     } else {
         float ae[CH][8], ao[CH][8], be[CH][8], bo[CH][8];
         load_half<CH>(pcm, n_sf, A.nch, 0, (long long)h * 1024 - 1024, ae, ao);
@@ -273,19 +282,27 @@ __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
         mdct_frame<CH>(ae, ao, be, bo, lds, A.T, c);
     }
     FrameState<CH> st;
+    int q[CH][16];
+    uint32_t sfw[CH];
+    SparsePlan P[CH];
     if (PASS == 1) {
 #pragma unroll
         for (int ch = 0; ch < CH; ch++) st.prev[ch] = 0.f;
-        finish_frame<CH, true>(c, lds, L, A, st, 0, 0, gframe, qbuf);
+        analyse_frame<CH, true, EXACT>(c, lds, L, A, 0, st, gframe, q, sfw, P);
         return;
     }
-    store_coeffs_dbg<CH>(c, A, gframe);
+    store_coeffs_dbg<CH>(c, A, gframe, 0);
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) st.prev[ch] = lane < 25 ? A.s_prev[(gframe * A.nch + ch) * 32 + lane] : 0.f;
-    const uint32_t flen = finish_frame<CH, false>(c, lds, L, A, st, 0, 0, gframe, qbuf);
+    analyse_frame<CH, false, EXACT>(c, lds, L, A, 0, st, gframe, q, sfw, P);
+    uint32_t tot[2];
+    tot[0] = P[0].total;
+    tot[1] = P[CH - 1].total;
+    const uint32_t flen = emit_frame<CH>(stage, CH, 0, tot, sfw, P, q);
+    wave_sync();
     if (lane == 0) A.frame_size[gframe] = flen;
     const uint32_t n16 = (flen + 15) >> 4;
-    const uint4 *src = reinterpret_cast<const uint4 *>(lds.u.stage);
+    const uint4 *src = reinterpret_cast<const uint4 *>(stage);
     uint4 *dst = reinterpret_cast<uint4 *>(A.slots + gframe * (unsigned long long)kFrameCap);
     for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
 }
@@ -345,7 +362,7 @@ __global__ void lossy_frame_offsets_kernel(LossyArgs A) {
 // forward MDCT of independent 2048-sample mono windows (flo_mdct_forward)
 __global__ __launch_bounds__(64) void mdct_only_kernel(LossyDevTables T, const float *frames, unsigned long long n,
                                                        float *out) {
-    __shared__ LossyLds<1> lds;
+    __shared__ WaveLds<1> lds;
     const unsigned long long w = blockIdx.x;
     if (w >= n) return;
     const int lane = lane_id();
@@ -364,21 +381,16 @@ __global__ __launch_bounds__(64) void mdct_only_kernel(LossyDevTables T, const f
 __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigned long long n, uint8_t *slots,
                                                          uint32_t *sizes) {
     __shared__ uint8_t stage[2080];
-    __shared__ int16_t qb[1024];
     const unsigned long long w = blockIdx.x;
     if (w >= n) return;
     const int lane = lane_id();
     int v[16];
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-        v[e] = q[w * 1024 + 16 * lane + e];
-        qb[16 * lane + e] = (int16_t)v[e];
-    }
+    for (int e = 0; e < 16; e++) v[e] = q[w * 1024 + 16 * lane + e];
     SparsePlan P;
     sparse_plan(v, P);
-    __syncthreads();
-    sparse_emit(qb + 16 * lane, P, stage);
-    __syncthreads();
+    sparse_emit(v, P, stage);
+    wave_sync();
     for (uint32_t i = lane; i < P.total; i += 64) slots[w * 2080 + i] = stage[i];
     if (lane == 0) sizes[w] = P.total;
 }
@@ -406,20 +418,27 @@ __global__ void synth_fill_kernel(float *pcm, const unsigned long long *clip_off
     } while (0)
 
 int launch_lossy_chain(const LossyArgs &A, hipStream_t s) {
-    if (A.nch == 1) hipLaunchKernelGGL(lossy_chain_kernel<1>, dim3(A.n_clips), dim3(64), 0, s, A);
-    else if (A.nch == 2) hipLaunchKernelGGL(lossy_chain_kernel<2>, dim3(A.n_clips), dim3(64), 0, s, A);
-    else return -1;
+    dim3 g(A.n_clips);
+    if (A.nch == 1) {
+        if (A.exact) hipLaunchKernelGGL((lossy_chain_kernel<1, true>), g, dim3(64), 0, s, A);
+        else hipLaunchKernelGGL((lossy_chain_kernel<1, false>), g, dim3(64), 0, s, A);
+    } else if (A.nch == 2) {
+        if (A.exact) hipLaunchKernelGGL((lossy_chain_kernel<2, true>), g, dim3(128), 0, s, A);
+        else hipLaunchKernelGGL((lossy_chain_kernel<2, false>), g, dim3(128), 0, s, A);
+    } else return -1;
     FLO_LAUNCH_CHECK();
     return 0;
 }
 int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s) {
     dim3 g((unsigned)A.total_frames), b(64);
     if (A.nch == 1) {
-        if (pass == 1) hipLaunchKernelGGL((lossy_frame_kernel<1, 1>), g, b, 0, s, A);
-        else hipLaunchKernelGGL((lossy_frame_kernel<1, 2>), g, b, 0, s, A);
+        if (pass == 1) hipLaunchKernelGGL((lossy_frame_kernel<1, 1, false>), g, b, 0, s, A);
+        else if (A.exact) hipLaunchKernelGGL((lossy_frame_kernel<1, 2, true>), g, b, 0, s, A);
+        else hipLaunchKernelGGL((lossy_frame_kernel<1, 2, false>), g, b, 0, s, A);
     } else if (A.nch == 2) {
-        if (pass == 1) hipLaunchKernelGGL((lossy_frame_kernel<2, 1>), g, b, 0, s, A);
-        else hipLaunchKernelGGL((lossy_frame_kernel<2, 2>), g, b, 0, s, A);
+        if (pass == 1) hipLaunchKernelGGL((lossy_frame_kernel<2, 1, false>), g, b, 0, s, A);
+        else if (A.exact) hipLaunchKernelGGL((lossy_frame_kernel<2, 2, true>), g, b, 0, s, A);
+        else hipLaunchKernelGGL((lossy_frame_kernel<2, 2, false>), g, b, 0, s, A);
     } else return -1;
     FLO_LAUNCH_CHECK();
     return 0;

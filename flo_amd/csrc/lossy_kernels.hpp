@@ -34,6 +34,7 @@ struct LossyArgs {
     short *dbg_q;                            // [total_frames][nch][1024]
     unsigned short *dbg_sfw;                 // [total_frames][nch][25]
     const float *in_coeffs;                  // when set: skip the transform, quantise these spectra
+    int exact;                               // re-decide near-threshold coefficients with the reference's dB expression
 };
 
 int launch_lossy_chain(const LossyArgs &A, hipStream_t s);
