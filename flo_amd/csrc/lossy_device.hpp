@@ -27,7 +27,8 @@ namespace flo {
 //   rows 12..15 : FFT pass-1 twiddles W512^(lane k), k = 1..7 (re,im pairs, last pair unused)
 //   rows 16..19 : FFT pass-2 twiddles W64^((lane&7) k), k = 1..7
 //   rows 20..23 : ATH amplitude thresholds of coefficients 16 lane .. 16 lane + 15
-constexpr int kPackRows = 24;
+//   rows 24..26 : per-lane band bookkeeping of the contiguous layout (see load_lane_const)
+constexpr int kPackRows = 27;
 
 struct LossyDevTables {
     const float4 *pack;      // [kPackRows][64]
@@ -64,13 +65,43 @@ struct WaveLds {
 };
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// The same value behind an optimisation barrier: inside the frame loop every lane-derived address is then
+// recomputed per frame (a few integer ops) instead of being hoisted into dozens of loop-invariant registers.
+__device__ __forceinline__ int lane_id_opaque() {
+    int l = (int)(threadIdx.x & 63);
+    asm volatile("" : "+v"(l));
+    return l;
+}
 
 // Ordering point between LDS accesses of ONE wavefront (lanes exchange data through LDS). The hardware executes a
 // wave's LDS instructions in order, so no s_barrier is needed; this only pins the compiler.
 __device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
+}
+// Workgroup barrier that orders LDS traffic only: outstanding global loads (the next half-frame's prefetch) and
+// stores (the previous frame's flush) stay in flight across it, unlike __syncthreads() which drains vmcnt(0).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------ cross-lane
+// DPP moves (no LDS round trip). Lanes whose source lane does not exist keep `old`.
+//   0x111..0x11F row_shr:n   0x101..0x10F row_shl:n   0x138 wave_shr:1   0x130 wave_shl:1
+//   0x142 row_bcast:15       0x143 row_bcast:31
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ int dpp_i(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));
+}
+// value of lane + 32 (lanes 0..31); lanes 32..63 receive lane - 32
+__device__ __forceinline__ float from_other_half(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return __int_as_float(lane_id() < 32 ? r[1] : r[0]);
 }
 
 // ------------------------------------------------------------------------------------------------ DFT-8
@@ -120,9 +151,8 @@ __device__ __forceinline__ void cmul(float &xr, float &xi, float wr, float wi) {
 //   pass 2: DFT over nb -> kb, twiddle W64^(nc*kb);             LDS exchange nc <-> kb
 //   pass 3: DFT over nc -> kc.
 template <int CH>
-__device__ __forceinline__ void fft512(float (&zr)[CH][8], float (&zi)[CH][8], float (*xch)[kXchFloats],
+__device__ __forceinline__ void fft512(const int lane, float (&zr)[CH][8], float (&zi)[CH][8], float (*xch)[kXchFloats],
                                        const LossyDevTables &T) {
-    const int lane = lane_id();
     // pass 1
 #pragma unroll
     for (int c = 0; c < CH; c++) dft8(zr[c], zi[c]);
@@ -213,9 +243,8 @@ __device__ __forceinline__ void half_offsets(int lane, int r, int &eo, int &oo) 
 // = pre-roll) that this lane folds: even-offset and odd-offset sample of each of its 8 rows, CH channels
 // starting at channel c0 of an nch-channel interleaved clip of n_frames_total sample-frames.
 template <int CH>
-__device__ __forceinline__ void load_half(const float *__restrict__ pcm, long long n_sf, int nch, int c0,
+__device__ __forceinline__ void load_half(const int lane, const float *__restrict__ pcm, long long n_sf, int nch, int c0,
                                           long long s0, float (&he)[CH][8], float (&ho)[CH][8]) {
-    const int lane = lane_id();
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         int eo, oo;
@@ -242,9 +271,8 @@ __device__ __forceinline__ void load_half(const float *__restrict__ pcm, long lo
 // Same, when every one of the 1024 sample-frames starting at s0 exists (all but the clip's last frame or two): no
 // per-lane predicates, the 16 loads issue back to back.
 template <int CH>
-__device__ __forceinline__ void load_half_fast(const float *__restrict__ pcm, int nch, int c0, long long s0,
+__device__ __forceinline__ void load_half_fast(const int lane, const float *__restrict__ pcm, int nch, int c0, long long s0,
                                                float (&he)[CH][8], float (&ho)[CH][8]) {
-    const int lane = lane_id();
     const float *base = pcm + s0 * nch + c0;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
@@ -267,10 +295,9 @@ __device__ __forceinline__ void load_half_fast(const float *__restrict__ pcm, in
 // Fold first half (ae, ao) and second half (be, bo) into the 8 complex FFT inputs of this lane
 // (window, butterflies and pre-rotation of mdct.rs:174-197, same operation order per element).
 template <int CH>
-__device__ __forceinline__ void fold(const float (&ae)[CH][8], const float (&ao)[CH][8], const float (&be)[CH][8],
+__device__ __forceinline__ void fold(const int lane, const float (&ae)[CH][8], const float (&ao)[CH][8], const float (&be)[CH][8],
                                      const float (&bo)[CH][8], float (&zr)[CH][8], float (&zi)[CH][8],
                                      const LossyDevTables &T) {
-    const int lane = lane_id();
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const float4 ww = T.pack[r * 64 + lane];
@@ -298,10 +325,9 @@ __device__ __forceinline__ void fold(const float (&ae)[CH][8], const float (&ao)
 // Post-rotation (mdct.rs:203-223) + transpose to the contiguous layout through LDS:
 //   out[2m] = -Z.re w.re - Z.im w.im,  out[1023 - 2m] = -Z.re w.im + Z.im w.re,   m = lane + 64 r
 template <int CH>
-__device__ __forceinline__ void post_rotate_transpose(const float (&zr)[CH][8], const float (&zi)[CH][8],
+__device__ __forceinline__ void post_rotate_transpose(const int lane, const float (&zr)[CH][8], const float (&zi)[CH][8],
                                                       float (*coef)[kCoefFloats], float (&c)[CH][16],
                                                       const LossyDevTables &T) {
-    const int lane = lane_id();
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int m = lane + 64 * r;
@@ -344,21 +370,16 @@ struct LaneConst {
 };
 // Band b is reduced by lane b (even slots of the band) and lane 32 + b (odd slots); lane b adds the two halves.
 
-__device__ __forceinline__ void load_lane_const(LaneConst &L, const LossyDevTables &T) {
-    const int lane = lane_id();
-    L.bnd = T.lane_bnd[lane];
-    L.slot0 = T.lane_slot0[lane];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint32_t b0 = T.band[16 * lane + 2 * i], b1 = T.band[16 * lane + 2 * i + 1];
-        L.boff[i] = (b0 * 8u) | ((b1 * 8u) << 16);
-    }
-    const int bl = lane & 31;
-    const int b = bl < 25 ? bl : 24;
-    const float cnt = T.band_count[b];
-    L.rcount = cnt > 0.f ? 1.0f / cnt : 0.f;
-    L.bs0 = T.band_slot0[b] + (lane >> 5);
-    L.bs1 = bl < 25 ? T.band_slot0[b + 1] : 0u;
+__device__ __forceinline__ void load_lane_const(const int lane, LaneConst &L, const LossyDevTables &T) {
+    // pack rows 24..26 (built by tables.cpp): 8 x boff | bnd, slot0, 1/count, bs0 | bs1 << 16
+    const float4 a = T.pack[24 * 64 + lane], b = T.pack[25 * 64 + lane], c = T.pack[26 * 64 + lane];
+    L.boff[0] = __float_as_uint(a.x); L.boff[1] = __float_as_uint(a.y); L.boff[2] = __float_as_uint(a.z); L.boff[3] = __float_as_uint(a.w);
+    L.boff[4] = __float_as_uint(b.x); L.boff[5] = __float_as_uint(b.y); L.boff[6] = __float_as_uint(b.z); L.boff[7] = __float_as_uint(b.w);
+    L.bnd = __float_as_uint(c.x);
+    L.slot0 = __float_as_uint(c.y);
+    L.rcount = c.z;
+    L.bs0 = __float_as_uint(c.w) & 0xFFFFu;
+    L.bs1 = __float_as_uint(c.w) >> 16;
 }
 
 // Band energy (sum of c^2) and band maximum |c| (psychoacoustic.rs:155-163, encoder.rs:111-118).
@@ -412,8 +433,8 @@ __device__ __forceinline__ void band_stats(const float (&c)[CH][16], float2 (*sl
     }
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
-        energy[ch] += __shfl_down(energy[ch], 32);
-        bmax[ch] = fmaxf(bmax[ch], __shfl_down(bmax[ch], 32));
+        energy[ch] += from_other_half(energy[ch]);   // lanes 0..24: even-slot half + odd-slot half
+        bmax[ch] = fmaxf(bmax[ch], from_other_half(bmax[ch]));
     }
     wave_sync();
 }
@@ -421,32 +442,33 @@ __device__ __forceinline__ void band_stats(const float (&c)[CH][16], float2 (*sl
 // Spreading + masking offset (psychoacoustic.rs:166-194): lanes 0..24 in, a[band] out (before temporal masking).
 // 10 log10(e / n) is evaluated as (10 log10 2) * log2(e * (1/n)) with the hardware log2 (1 ulp): the thresholds it
 // feeds are compared at the 1e-6 level by both implementations.
-__device__ __forceinline__ float spread_threshold(float energy, float rcount, const LossyDevTables &T) {
-    const int lane = lane_id();
+__device__ __forceinline__ float spread_threshold(const int lane, float energy, float rcount, const LossyDevTables &T) {
     const bool is_band = lane < 25;
     float band_db = -100.0f;
     if (is_band && rcount > 0.f && energy > 1e-10f) band_db = 3.01029995663981195f * __builtin_amdgcn_logf(energy * rcount);
     if (!is_band) band_db = -__builtin_inff();
-    // suffix maximum: bands j >= i mask band i at full strength (spreading[j][i] = 1 for j >= i)
+    // suffix maximum: bands j >= i mask band i at full strength (spreading[j][i] = 1 for j >= i). Within each row of
+    // 16 lanes by row_shl steps; row 0 then takes the maximum of bands 16..24 from lane 16.
+    const float ninf = -__builtin_inff();
     float sm = band_db;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-        float t = __shfl_down(sm, d);
-        if (lane + d < 25) sm = fmaxf(sm, t);
-    }
+    sm = fmaxf(sm, dpp_f<0x101>(ninf, sm));
+    sm = fmaxf(sm, dpp_f<0x102>(ninf, sm));
+    sm = fmaxf(sm, dpp_f<0x104>(ninf, sm));
+    sm = fmaxf(sm, dpp_f<0x108>(ninf, sm));
+    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 16));
+    if (lane < 16) sm = fmaxf(sm, hi);
     // bands j < i: band_db[j] + s10d[i-j]; only deltas with band_db_max + s10d[d] > -100 can matter
-    float gmax = __shfl(sm, 0);
+    const float gmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 0));
     int dmax = 24;
     if (gmax < 500.f) {
         int d = (int)((gmax + 100.0f) * (1.0f / 24.9f)) + 1;
         dmax = d < 1 ? 1 : (d > 24 ? 24 : d);
     }
-    dmax = __builtin_amdgcn_readfirstlane(dmax);
     float m = fmaxf(-100.0f, sm);
+    float cur = band_db;
     for (int d = 1; d <= dmax; d++) {
-        float v = __shfl_up(band_db, d);
-        float s = T.s10d[d];
-        if (lane >= d) m = fmaxf(m, v + s);
+        cur = dpp_f<0x138>(ninf, cur);  // wave_shr:1 -> band_db[lane - d]
+        m = fmaxf(m, cur + T.s10d[d]);
     }
     return m + (-6.0f);
 }
@@ -482,9 +504,8 @@ __device__ __forceinline__ float round_away(float x) {
 // threshold are re-decided with the reference's own f32 expression (used by the stage tests).
 // No clamp is needed after rounding: |c * 30000/band_max| <= 30000 (1 + 2^-23), and band_max <= 1e-10 gives sf = 1.
 template <int CH, bool EXACT>
-__device__ __forceinline__ void quantise(const float (&c)[CH][16], const WaveLds<CH> &lds, const LaneConst &L,
+__device__ __forceinline__ void quantise(const int lane, const float (&c)[CH][16], const WaveLds<CH> &lds, const LaneConst &L,
                                          const LossyDevTables &T, int (&q)[CH][16]) {
-    const int lane = lane_id();
     float al[16];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -521,42 +542,16 @@ __device__ __forceinline__ void quantise(const float (&c)[CH][16], const WaveLds
 }
 
 // ------------------------------------------------------------------------------------------------ sparse RLE
-// inclusive prefix sum over the wave
-__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-__device__ __forceinline__ int wave_excl_max_up(int v, int ident) {  // max over lanes < lane
-    const int lane = lane_id();
-    int x = __shfl_up(v, 1);
-    if (lane == 0) x = ident;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(x, d);
-        if (lane >= d) x = max(x, t);
-    }
-    return x;
-}
-// two independent u16 minima over lanes > lane, packed in one register (positions are <= 1024)
-typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t wave_excl_min2_down(uint32_t packed, uint32_t ident) {
-    const int lane = lane_id();
-    uint32_t x = __shfl_down(packed, 1);
-    if (lane == 63) x = ident;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_down(x, d);
-        if (lane + d < 64) {
-            ushort2_t a = __builtin_bit_cast(ushort2_t, x), b = __builtin_bit_cast(ushort2_t, t);
-            x = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(a, b));
-        }
-    }
-    return x;
+// inclusive prefix sum over the wave: Hillis-Steele inside each row of 16 lanes, then two row broadcasts
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
+    int v = (int)x;
+    v += dpp_i<0x111>(0, v);
+    v += dpp_i<0x112>(0, v);
+    v += dpp_i<0x114>(0, v);
+    v += dpp_i<0x118>(0, v);
+    v += dpp_i<0x142, 0xA>(0, v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_i<0x143, 0xC>(0, v);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)v;
 }
 
 // serialize_sparse (encoder.rs:284-314) of the 1024 values of one channel held 16 per lane.
@@ -575,25 +570,30 @@ struct SparsePlan {
     uint32_t total;    // total sparse bytes (uniform)
 };
 
-__device__ __forceinline__ void sparse_plan(const int (&q)[16], SparsePlan &P) {
-    const int lane = lane_id();
+__device__ __forceinline__ void sparse_plan(const int lane, const int (&q)[16], SparsePlan &P) {
     uint32_t m = 0;
 #pragma unroll
     for (int e = 0; e < 16; e++) m |= (q[e] != 0 ? 1u : 0u) << e;
-    const uint32_t prev_m = __shfl_up(m, 1);
-    const uint32_t prev_nz = lane == 0 ? 0u : (prev_m >> 15) & 1u;
+    const uint32_t prev_m = (uint32_t)dpp_i<0x138>(0, (int)m);  // mask of lane - 1 (0 for lane 0)
+    const uint32_t prev_nz = (prev_m >> 15) & 1u;
     uint32_t zs = ~m & ((m << 1) | prev_nz) & 0xFFFFu;
     if (lane == 0 && !(m & 1u)) zs |= 1u;  // the walk starts with a zero run
     const int base = 16 * lane;
-    // look-ahead / look-behind over the other lanes
+    // look-ahead / look-behind over the other lanes: find the neighbouring lane from ballots, then fetch its answer
     const uint32_t inv = ~m & 0xFFFFu;
-    const uint32_t first_nz = m ? (uint32_t)(base + __builtin_ctz(m)) : 1024u;
-    const uint32_t first_z = inv ? (uint32_t)(base + __builtin_ctz(inv)) : 1024u;
+    const int first_nz = m ? base + __builtin_ctz(m) : 1024;
+    const int first_z = inv ? base + __builtin_ctz(inv) : 1024;
     const int last_z = inv ? base + 31 - __builtin_clz(inv) : -1;
-    const uint32_t nxt = wave_excl_min2_down(first_nz | (first_z << 16), 1024u | (1024u << 16));
-    P.nn = (int)(nxt & 0xFFFFu);
-    P.nz_end = (int)(nxt >> 16);
-    const int lz_before = wave_excl_max_up(last_z, -1);
+    const unsigned long long has_nz = __ballot(m != 0u), has_z = __ballot(inv != 0u);
+    const unsigned long long nz_above = (has_nz >> 1) >> lane, z_above = (has_z >> 1) >> lane;
+    const unsigned long long z_below = lane ? has_z << (64 - lane) : 0ull;
+    const int ln_nz = nz_above ? lane + 1 + __builtin_ctzll(nz_above) : lane;
+    const int ln_z = z_above ? lane + 1 + __builtin_ctzll(z_above) : lane;
+    const int ln_zb = z_below ? lane - 1 - __builtin_clzll(z_below) : lane;
+    const int f_nz = __shfl(first_nz, ln_nz), f_z = __shfl(first_z, ln_z), l_z = __shfl(last_z, ln_zb);
+    P.nn = nz_above ? f_nz : 1024;
+    P.nz_end = z_above ? f_z : 1024;
+    const int lz_before = z_below ? l_z : -1;
     const int t_in = base - 1 - lz_before;  // length of the non-zero run ending just before this lane
     // 255-cap continuation: a position i in the leading non-zeros with (t_in + i) % 255 == 0 and t_in + i > 0
     const int ln = inv ? __builtin_ctz(inv) : 16;
@@ -622,13 +622,12 @@ __device__ __forceinline__ void sparse_plan(const int (&q)[16], SparsePlan &P) {
     }
     const uint32_t incl = wave_incl_sum(bytes);
     P.off0 = incl - bytes;
-    P.total = __shfl(incl, 63);
+    P.total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 }
 
 // Emit this lane's part of the sparse blob to `dst` (LDS bytes; the blob starts at dst[0]). qv = this lane's 16
 // values parked in LDS (the header loop fetches nothing from it; the value loop is static).
-__device__ __forceinline__ void sparse_emit(const int (&q)[16], const SparsePlan &P, uint8_t *dst) {
-    const int lane = lane_id();
+__device__ __forceinline__ void sparse_emit(const int lane, const int (&q)[16], const SparsePlan &P, uint8_t *dst) {
     const int base = 16 * lane;
     const uint32_t m = P.M & 0xFFFFu;
     // record headers

@@ -12,6 +12,14 @@
 #include "lossy_kernels.hpp"
 #include "../../include/flo_synth.h"
 
+// Diagnostic builds only (never shipped): FLO_ABLATE=n cuts the chain kernel's frame body short so that phase costs can
+// be read from timing differences; intermediate values are kept alive so nothing upstream is optimised away.
+//   0 full | 1 no flush/barriers | 2 no emit | 3 no sparse plan | 4 no quantise | 5 no band stats/psy | 6 loads+fold only
+#ifndef FLO_ABLATE
+#define FLO_ABLATE 0
+#endif
+#define FLO_KEEP(x) asm volatile("" ::"v"(x))
+
 namespace flo {
 
 // ---------------------------------------------------------------------------------------------- frame body
@@ -23,17 +31,15 @@ struct FrameState {
 // Everything between the MDCT and the byte stream for CH channels held by this wave: band statistics, masking
 // level, temporal masking, scale factors, quantiser, sparse-RLE plan. ch0 = index of c[0] among the clip's channels.
 template <int CH, bool BANDS_ONLY, bool EXACT>
-__device__ __forceinline__ void analyse_frame(float (&c)[CH][16], WaveLds<CH> &lds, const LaneConst &L,
-                                              const LossyArgs &A, int ch0, FrameState<CH> &st,
+__device__ __forceinline__ void analyse_frame(const int lane, float (&c)[CH][16], WaveLds<CH> &lds, const LaneConst &L,
+                                              const LossyArgs &A, const LossyDevTables &T, int ch0, FrameState<CH> &st,
                                               unsigned long long gframe, int (&q)[CH][16], uint32_t (&sfw)[CH],
                                               SparsePlan (&P)[CH]) {
-    const int lane = lane_id();
-    const LossyDevTables &T = A.T;
     float energy[CH], bmax[CH];
     band_stats<CH>(c, lds.slots, L, T.max_band_slots, energy, bmax);
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
-        float a = spread_threshold(energy[ch], L.rcount, T);
+        float a = spread_threshold(lane, energy[ch], L.rcount, T);
         if (BANDS_ONLY) {
             if (lane < 25) A.a_t[(gframe * A.nch + ch0 + ch) * 32 + lane] = a;
             continue;
@@ -52,7 +58,15 @@ __device__ __forceinline__ void analyse_frame(float (&c)[CH][16], WaveLds<CH> &l
     }
     if (BANDS_ONLY) return;
     wave_sync();
-    quantise<CH, EXACT>(c, lds, L, T, q);
+#if FLO_ABLATE >= 4
+    for (int ch = 0; ch < CH; ch++) { FLO_KEEP(sfw[ch]); for (int e = 0; e < 16; e++) q[ch][e] = 0; P[ch].total = 3; P[ch].off0 = 0; P[ch].M = 0; }
+    return;
+#endif
+    quantise<CH, EXACT>(lane, c, lds, L, T, q);
+#if FLO_ABLATE >= 3
+    for (int ch = 0; ch < CH; ch++) { P[ch].total = 3; P[ch].off0 = 0; P[ch].M = 0; }
+    return;
+#endif
     if (A.dbg_q) {
 #pragma unroll
         for (int ch = 0; ch < CH; ch++) {
@@ -66,17 +80,16 @@ __device__ __forceinline__ void analyse_frame(float (&c)[CH][16], WaveLds<CH> &l
         for (int ch = 0; ch < CH; ch++) A.dbg_sfw[(gframe * A.nch + ch0 + ch) * 25 + lane] = (unsigned short)sfw[ch];
     }
 #pragma unroll
-    for (int ch = 0; ch < CH; ch++) sparse_plan(q[ch], P[ch]);
+    for (int ch = 0; ch < CH; ch++) sparse_plan(lane, q[ch], P[ch]);
 }
 
 // Write this wave's share of the frame bytes (writer.rs:236-254 + encoder.rs:243-280) into the staging buffer.
 // tot[c] = sparse bytes of channel c for ALL nch channels of the frame (uniform); the wave that holds channel 0
 // also writes the frame and blob headers. Returns the frame length.
 template <int CH>
-__device__ __forceinline__ uint32_t emit_frame(uint8_t *f, int nch, int ch0, const uint32_t *tot,
+__device__ __forceinline__ uint32_t emit_frame(const int lane, uint8_t *f, int nch, int ch0, const uint32_t *tot,
                                                const uint32_t (&sfw)[CH], const SparsePlan (&P)[CH],
                                                const int (&q)[CH][16]) {
-    const int lane = lane_id();
     uint32_t pos = 12 + 50 * (uint32_t)nch;
     uint32_t chpos[2];
     for (int c = 0; c < nch; c++) {
@@ -104,27 +117,26 @@ __device__ __forceinline__ uint32_t emit_frame(uint8_t *f, int nch, int ch0, con
             uint8_t *p = f + chpos[c];
             p[0] = (uint8_t)l; p[1] = (uint8_t)(l >> 8); p[2] = (uint8_t)(l >> 16); p[3] = (uint8_t)(l >> 24);
         }
-        sparse_emit(q[ch], P[ch], f + chpos[c] + 4);
+        sparse_emit(lane, q[ch], P[ch], f + chpos[c] + 4);
     }
     return flen;
 }
 
 // MDCT of one frame of CH channels: halves (ae,ao) + (be,bo) -> c (contiguous layout)
 template <int CH>
-__device__ __forceinline__ void mdct_frame(const float (&ae)[CH][8], const float (&ao)[CH][8],
+__device__ __forceinline__ void mdct_frame(const int lane, const float (&ae)[CH][8], const float (&ao)[CH][8],
                                            const float (&be)[CH][8], const float (&bo)[CH][8], WaveLds<CH> &lds,
                                            const LossyDevTables &T, float (&c)[CH][16]) {
     float zr[CH][8], zi[CH][8];
-    fold<CH>(ae, ao, be, bo, zr, zi, T);
-    fft512<CH>(zr, zi, lds.u.xch, T);
-    post_rotate_transpose<CH>(zr, zi, lds.u.coef, c, T);
+    fold<CH>(lane, ae, ao, be, bo, zr, zi, T);
+    fft512<CH>(lane, zr, zi, lds.u.xch, T);
+    post_rotate_transpose<CH>(lane, zr, zi, lds.u.coef, c, T);
 }
 
 template <int CH>
-__device__ __forceinline__ void store_coeffs_dbg(const float (&c)[CH][16], const LossyArgs &A,
+__device__ __forceinline__ void store_coeffs_dbg(const int lane, const float (&c)[CH][16], const LossyArgs &A,
                                                  unsigned long long gframe, int ch0) {
     if (!A.dbg_coeffs) return;
-    const int lane = lane_id();
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
         float4 *d = reinterpret_cast<float4 *>(A.dbg_coeffs + (gframe * A.nch + ch0 + ch) * 1024 + 16 * lane);
@@ -134,8 +146,7 @@ __device__ __forceinline__ void store_coeffs_dbg(const float (&c)[CH][16], const
 }
 
 template <int CH>
-__device__ __forceinline__ void load_coeffs(float (&c)[CH][16], const LossyArgs &A, unsigned long long gframe, int ch0) {
-    const int lane = lane_id();
+__device__ __forceinline__ void load_coeffs(const int lane, float (&c)[CH][16], const LossyArgs &A, unsigned long long gframe, int ch0) {
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
         const float4 *s = reinterpret_cast<const float4 *>(A.in_coeffs + (gframe * A.nch + ch0 + ch) * 1024 + 16 * lane);
@@ -147,63 +158,100 @@ __device__ __forceinline__ void load_coeffs(float (&c)[CH][16], const LossyArgs 
     }
 }
 
-// Add an opaque zero to the table pointers once per frame: the loads then depend on a value the compiler cannot
-// see through, so they stay inside the frame loop (served by L1/L2) instead of being hoisted into ~100 registers.
-// The pointers keep their global address space (laundering the pointer itself degrades them to flat loads).
-__device__ __forceinline__ void launder_tables(LossyDevTables &T) {
-    unsigned zero = 0;
-    asm volatile("" : "+s"(zero));
-    T.pack += zero;
-    T.ath_db += zero;
-    T.s10d += zero;
+// ---------------------------------------------------------------------------------------------- chain kernel
+// One wavefront per (clip, channel); a workgroup hosts G clips (NW = channels = 1 or 2 waves each) that share ONE
+// copy of the constant pack in LDS (27 KiB: window, twiddles, ATH thresholds, band bookkeeping), so the only
+// global traffic of the frame loop is the PCM stream in and the bitstream out. Each wave walks its channel's
+// frames in order: the raw samples of the overlapping half-frame and the 25-float masking state stay in registers,
+// so every PCM sample is read from HBM once. The two waves of a stereo clip meet three times per frame (LDS flag
+// hand-shakes, no workgroup barrier: other clips of the workgroup never wait) to assemble and flush the frame.
+constexpr int kPackBytes = kPackRows * 64 * 16;
+struct ClipLds {
+    WaveLds<1> wl[2];
+    __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64];
+    uint32_t tot[2];
+    uint32_t cnt[2];
+};
+static_assert(sizeof(ClipLds) % 16 == 0, "clip LDS block keeps 16-byte alignment");
+
+// Rendezvous of the two waves of one clip: publish my step, wait for the partner's. Both waves are resident in the
+// same workgroup, so the wait cannot deadlock; LDS is one unit per CU, so a wave's earlier LDS writes are visible
+// to whoever observes its counter.
+__device__ __forceinline__ void pair_sync(uint32_t *cnt, int w, uint32_t step) {
+    // explicit DS instructions: a volatile access through a generic pointer would become a system-scope flat load
+    const uint32_t mine = (uint32_t)(uintptr_t)(cnt + w), theirs = (uint32_t)(uintptr_t)(cnt + (w ^ 1));
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(mine), "v"(step) : "memory");
+    uint32_t seen;
+    do {
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(theirs) : "memory");
+        if (seen >= step) break;
+        __builtin_amdgcn_s_sleep(1);
+    } while (true);
 }
 
-// ---------------------------------------------------------------------------------------------- chain kernel
-// One workgroup per clip, one wavefront per channel (NW = channels = 1 or 2). Each wave walks its channel's frames
-// in order: raw samples of the overlapping half-frame and the 25-float masking state stay in registers, so every
-// PCM sample is read from HBM once. The waves meet three times per frame to assemble and flush the frame bytes.
 #ifndef FLO_CHAIN_WAVES_PER_SIMD
 #define FLO_CHAIN_WAVES_PER_SIMD 3
 #endif
 template <int NW, bool EXACT>
-__global__ __launch_bounds__(64 * NW, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_kernel(LossyArgs A) {
-    __shared__ WaveLds<1> wl[NW];
-    __shared__ __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64];
-    __shared__ uint32_t tot_sh[2];
-    const int lane = lane_id();
-    const int w = NW == 1 ? 0 : (int)(threadIdx.x >> 6);  // channel of this wave
+__global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_kernel(LossyArgs A, int clips_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int tid = (int)threadIdx.x;
-    const unsigned clip = blockIdx.x;
+    const int lane = tid & 63;
+    // constant pack -> LDS (all waves of the workgroup, once)
+    {
+        float4 *dstp = reinterpret_cast<float4 *>(lds_raw);
+        for (int i = tid; i < kPackRows * 64; i += (int)blockDim.x) dstp[i] = A.T.pack[i];
+        // rendezvous counters must be zero before any wave can look at its partner's
+        for (int i = tid; i < clips_per_wg; i += (int)blockDim.x) {
+            ClipLds &c0 = *reinterpret_cast<ClipLds *>(lds_raw + kPackBytes + (size_t)i * sizeof(ClipLds));
+            c0.cnt[0] = 0;
+            c0.cnt[1] = 0;
+        }
+    }
+    __syncthreads();
+    const int wv = tid >> 6;
+    const int cl = wv / NW;                 // clip slot inside the workgroup
+    const int w = NW == 1 ? 0 : wv % NW;    // channel of this wave
+    const unsigned clip = blockIdx.x * (unsigned)clips_per_wg + (unsigned)cl;
+    if (clip >= (unsigned)A.n_clips) return;
+    ClipLds &cs = *reinterpret_cast<ClipLds *>(lds_raw + kPackBytes + (size_t)cl * sizeof(ClipLds));
+    WaveLds<1> &lds = cs.wl[w];
+    uint8_t *stage = cs.stage;
+    LossyDevTables T = A.T;
+    T.pack = reinterpret_cast<const float4 *>(lds_raw);
+
     const float *pcm = A.pcm + A.clip_off[clip];
     const long long n_sf = (long long)A.clip_nsf[clip];
     const unsigned hops = A.clip_hops[clip];
     const unsigned long long frame0 = A.clip_frame0[clip];
     uint8_t *gout = A.out + A.out_off[clip];
-    WaveLds<1> &lds = wl[w];
+    const int ptid = NW == 1 ? lane : (w * 64 + lane);  // thread index inside the clip's wave pair
 
-    LaneConst L;
-    load_lane_const(L, A.T);
     FrameState<1> st;
     st.prev[0] = 0.f;
-
     float ae[1][8], ao[1][8], be[1][8], bo[1][8];
 #pragma unroll
     for (int r = 0; r < 8; r++) ae[0][r] = ao[0][r] = 0.f;  // pre-roll: 1024 zeros (encoder.rs:177)
     if (!A.in_coeffs) {
-        if (n_sf >= 1024) load_half_fast<1>(pcm, NW, w, 0, be, bo);
-        else load_half<1>(pcm, n_sf, NW, w, 0, be, bo);
+        if (n_sf >= 1024) load_half_fast<1>(lane, pcm, NW, w, 0, be, bo);
+        else load_half<1>(lane, pcm, n_sf, NW, w, 0, be, bo);
     }
-
     unsigned long long written = 0;
-    uint32_t pend = 0;
+    uint32_t pend = 0, step = 0;
     for (unsigned h = 0; h < hops; h++) {
-        launder_tables(A.T);
+        const int ln = lane_id_opaque();
+        {
+            unsigned zero = 0;  // keep the (rarely used) global tables out of loop-invariant registers
+            asm volatile("" : "+s"(zero));
+            T.ath_db += zero;
+            T.s10d += zero;
+        }
         float c[1][16];
         if (A.in_coeffs) {
-            load_coeffs<1>(c, A, frame0 + h, w);
+            load_coeffs<1>(ln, c, A, frame0 + h, w);
         } else {
             float zr[1][8], zi[1][8];
-            fold<1>(ae, ao, be, bo, zr, zi, A.T);
+            fold<1>(ln, ae, ao, be, bo, zr, zi, T);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 ae[0][r] = be[0][r];
@@ -212,42 +260,66 @@ __global__ __launch_bounds__(64 * NW, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain
             // issue the next half-frame's loads now; they are consumed at the top of the next iteration
             if (h + 1 < hops) {
                 const long long s0 = (long long)(h + 1) * 1024;
-                if (s0 + 1024 <= n_sf) load_half_fast<1>(pcm, NW, w, s0, be, bo);
-                else load_half<1>(pcm, n_sf, NW, w, s0, be, bo);
+                if (s0 + 1024 <= n_sf) load_half_fast<1>(ln, pcm, NW, w, s0, be, bo);
+                else load_half<1>(ln, pcm, n_sf, NW, w, s0, be, bo);
             }
-            fft512<1>(zr, zi, lds.u.xch, A.T);
-            post_rotate_transpose<1>(zr, zi, lds.u.coef, c, A.T);
-            store_coeffs_dbg<1>(c, A, frame0 + h, w);
+#if FLO_ABLATE >= 6
+            for (int r = 0; r < 8; r++) { FLO_KEEP(zr[0][r]); FLO_KEEP(zi[0][r]); }
+            continue;
+#endif
+            fft512<1>(ln, zr, zi, lds.u.xch, T);
+            post_rotate_transpose<1>(ln, zr, zi, lds.u.coef, c, T);
+            store_coeffs_dbg<1>(ln, c, A, frame0 + h, w);
         }
+#if FLO_ABLATE >= 5
+        for (int e = 0; e < 16; e++) FLO_KEEP(c[0][e]);
+        continue;
+#endif
         int q[1][16];
         uint32_t sfw[1];
         SparsePlan P[1];
-        analyse_frame<1, false, EXACT>(c, lds, L, A, w, st, frame0 + h, q, sfw, P);
-        if (NW > 1) {
-            if (lane == 0) tot_sh[w] = P[0].total;
-            __syncthreads();
+        {
+            LaneConst L;
+            load_lane_const(ln, L, T);
+            analyse_frame<1, false, EXACT>(ln, c, lds, L, A, T, w, st, frame0 + h, q, sfw, P);
         }
+#if FLO_ABLATE >= 2
+        FLO_KEEP(P[0].total); FLO_KEEP(P[0].off0); FLO_KEEP(P[0].M); FLO_KEEP(sfw[0]);
+        for (int e = 0; e < 16; e++) FLO_KEEP(q[0][e]);
+        continue;
+#endif
         uint32_t tot[2];
-        tot[0] = NW > 1 ? tot_sh[0] : P[0].total;
-        tot[1] = NW > 1 ? tot_sh[1] : 0u;
-        const uint32_t flen = emit_frame<1>(stage + pend, NW, w, tot, sfw, P, q);
-        __syncthreads();
-        if (tid == 0) A.frame_size[frame0 + h] = flen;
+        if (NW > 1) {
+            if (ln == 0) cs.tot[w] = P[0].total;
+            pair_sync(cs.cnt, w, ++step);
+            tot[0] = cs.tot[0];
+            tot[1] = cs.tot[1];
+        } else {
+            tot[0] = P[0].total;
+            tot[1] = 0u;
+        }
+        const uint32_t flen = emit_frame<1>(ln, stage + pend, NW, w, tot, sfw, P, q);
+#if FLO_ABLATE >= 1
+        FLO_KEEP(flen);
+        continue;
+#endif
+        if (NW > 1) pair_sync(cs.cnt, w, ++step); else wave_sync();
+        if (ptid == 0) A.frame_size[frame0 + h] = flen;
         // flush complete 16-byte chunks, carry the rest at the front of the staging buffer
         const uint32_t have = pend + flen;
         const uint32_t n16 = have >> 4;
         const uint4 *src = reinterpret_cast<const uint4 *>(stage);
         uint4 *dst = reinterpret_cast<uint4 *>(gout + written);
-        for (uint32_t i = tid; i < n16; i += 64 * NW) dst[i] = src[i];
+        for (uint32_t i = ptid; i < n16; i += 64 * NW) dst[i] = src[i];
         pend = have & 15u;
-        const uint32_t tb = (tid < (int)pend) ? stage[(n16 << 4) + tid] : 0u;
+        const uint32_t tb = (ptid < (int)pend) ? stage[(n16 << 4) + ptid] : 0u;
         written += (unsigned long long)n16 << 4;
-        __syncthreads();
-        if (tid < (int)pend) stage[tid] = (uint8_t)tb;
+        if (NW > 1) pair_sync(cs.cnt, w, ++step); else wave_sync();
+        if (ptid < (int)pend) stage[ptid] = (uint8_t)tb;
     }
-    __syncthreads();
-    if (tid < (int)pend) gout[written + tid] = stage[tid];
-    if (tid == 0) A.clip_bytes[clip] = written + pend;
+    if (NW > 1) pair_sync(cs.cnt, w, ++step); else wave_sync();
+    if (ptid < (int)pend) gout[written + ptid] = stage[ptid];
+    if (ptid == 0) A.clip_bytes[clip] = written + pend;
 }
 
 // ---------------------------------------------------------------------------------------------- frame-parallel
@@ -271,15 +343,15 @@ __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
     const long long n_sf = (long long)A.clip_nsf[clip];
 
     LaneConst L;
-    load_lane_const(L, A.T);
+    load_lane_const(lane, L, A.T);
     float c[CH][16];
     if (A.in_coeffs) {
-        load_coeffs<CH>(c, A, gframe, 0);
+        load_coeffs<CH>(lane, c, A, gframe, 0);
     } else {
         float ae[CH][8], ao[CH][8], be[CH][8], bo[CH][8];
-        load_half<CH>(pcm, n_sf, A.nch, 0, (long long)h * 1024 - 1024, ae, ao);
-        load_half<CH>(pcm, n_sf, A.nch, 0, (long long)h * 1024, be, bo);
-        mdct_frame<CH>(ae, ao, be, bo, lds, A.T, c);
+        load_half<CH>(lane, pcm, n_sf, A.nch, 0, (long long)h * 1024 - 1024, ae, ao);
+        load_half<CH>(lane, pcm, n_sf, A.nch, 0, (long long)h * 1024, be, bo);
+        mdct_frame<CH>(lane, ae, ao, be, bo, lds, A.T, c);
     }
     FrameState<CH> st;
     int q[CH][16];
@@ -288,17 +360,17 @@ __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
     if (PASS == 1) {
 #pragma unroll
         for (int ch = 0; ch < CH; ch++) st.prev[ch] = 0.f;
-        analyse_frame<CH, true, EXACT>(c, lds, L, A, 0, st, gframe, q, sfw, P);
+        analyse_frame<CH, true, EXACT>(lane, c, lds, L, A, A.T, 0, st, gframe, q, sfw, P);
         return;
     }
-    store_coeffs_dbg<CH>(c, A, gframe, 0);
+    store_coeffs_dbg<CH>(lane, c, A, gframe, 0);
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) st.prev[ch] = lane < 25 ? A.s_prev[(gframe * A.nch + ch) * 32 + lane] : 0.f;
-    analyse_frame<CH, false, EXACT>(c, lds, L, A, 0, st, gframe, q, sfw, P);
+    analyse_frame<CH, false, EXACT>(lane, c, lds, L, A, A.T, 0, st, gframe, q, sfw, P);
     uint32_t tot[2];
     tot[0] = P[0].total;
     tot[1] = P[CH - 1].total;
-    const uint32_t flen = emit_frame<CH>(stage, CH, 0, tot, sfw, P, q);
+    const uint32_t flen = emit_frame<CH>(lane, stage, CH, 0, tot, sfw, P, q);
     wave_sync();
     if (lane == 0) A.frame_size[gframe] = flen;
     const uint32_t n16 = (flen + 15) >> 4;
@@ -368,10 +440,10 @@ __global__ __launch_bounds__(64) void mdct_only_kernel(LossyDevTables T, const f
     const int lane = lane_id();
     float ae[1][8], ao[1][8], be[1][8], bo[1][8];
     const float *p = frames + w * 2048;
-    load_half<1>(p, 2048, 1, 0, 0, ae, ao);
-    load_half<1>(p, 2048, 1, 0, 1024, be, bo);
+    load_half<1>(lane, p, 2048, 1, 0, 0, ae, ao);
+    load_half<1>(lane, p, 2048, 1, 0, 1024, be, bo);
     float c[1][16];
-    mdct_frame<1>(ae, ao, be, bo, lds, T, c);
+    mdct_frame<1>(lane, ae, ao, be, bo, lds, T, c);
     float4 *d = reinterpret_cast<float4 *>(out + w * 1024 + 16 * lane);
 #pragma unroll
     for (int q = 0; q < 4; q++) d[q] = make_float4(c[0][4 * q], c[0][4 * q + 1], c[0][4 * q + 2], c[0][4 * q + 3]);
@@ -388,8 +460,8 @@ __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigne
 #pragma unroll
     for (int e = 0; e < 16; e++) v[e] = q[w * 1024 + 16 * lane + e];
     SparsePlan P;
-    sparse_plan(v, P);
-    sparse_emit(v, P, stage);
+    sparse_plan(lane, v, P);
+    sparse_emit(lane, v, P, stage);
     wave_sync();
     for (uint32_t i = lane; i < P.total; i += 64) slots[w * 2080 + i] = stage[i];
     if (lane == 0) sizes[w] = P.total;
@@ -417,17 +489,36 @@ __global__ void synth_fill_kernel(float *pcm, const unsigned long long *clip_off
         if (e_ != hipSuccess) return (int)e_;  \
     } while (0)
 
-int launch_lossy_chain(const LossyArgs &A, hipStream_t s) {
-    dim3 g(A.n_clips);
-    if (A.nch == 1) {
-        if (A.exact) hipLaunchKernelGGL((lossy_chain_kernel<1, true>), g, dim3(64), 0, s, A);
-        else hipLaunchKernelGGL((lossy_chain_kernel<1, false>), g, dim3(64), 0, s, A);
-    } else if (A.nch == 2) {
-        if (A.exact) hipLaunchKernelGGL((lossy_chain_kernel<2, true>), g, dim3(128), 0, s, A);
-        else hipLaunchKernelGGL((lossy_chain_kernel<2, false>), g, dim3(128), 0, s, A);
-    } else return -1;
+// clips per workgroup: as few as fill the chip once (256 CUs), at most what 160 KiB of LDS holds
+int chain_clips_per_wg(int n_clips) {
+    int g = (n_clips + 255) / 256;
+    const int gmax = (int)((160 * 1024 - kPackBytes) / sizeof(ClipLds));
+    if (g > gmax) g = gmax;
+    if (g * 2 * 64 > 768) g = 6;   // the kernel is built for at most 768 threads (12 waves = 3 per SIMD)
+    return g < 1 ? 1 : g;
+}
+
+template <int NW, bool EXACT>
+static int launch_chain_t(const LossyArgs &A, hipStream_t s) {
+    const int g = chain_clips_per_wg(A.n_clips);
+    const size_t lds = kPackBytes + (size_t)g * sizeof(ClipLds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lossy_chain_kernel<NW, EXACT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const unsigned wgs = (unsigned)((A.n_clips + g - 1) / g);
+    hipLaunchKernelGGL((lossy_chain_kernel<NW, EXACT>), dim3(wgs), dim3(64 * NW * g), lds, s, A, g);
     FLO_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_lossy_chain(const LossyArgs &A, hipStream_t s) {
+    if (A.nch == 1) return A.exact ? launch_chain_t<1, true>(A, s) : launch_chain_t<1, false>(A, s);
+    if (A.nch == 2) return A.exact ? launch_chain_t<2, true>(A, s) : launch_chain_t<2, false>(A, s);
+    return -1;
 }
 int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s) {
     dim3 g((unsigned)A.total_frames), b(64);

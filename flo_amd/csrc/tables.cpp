@@ -3,6 +3,7 @@
 #include "tables.hpp"
 
 #include <cmath>
+#include <cstring>
 
 namespace flo {
 
@@ -105,7 +106,7 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
     }
 
     // per-lane constant pack [row][lane][4] (layout documented in lossy_device.hpp)
-    t.pack.assign(24 * 64 * 4, 0.0f);
+    t.pack.assign(27 * 64 * 4, 0.0f);
     auto P = [&](int row, int lane, int i) -> float & { return t.pack[((size_t)row * 64 + lane) * 4 + i]; };
     for (int lane = 0; lane < 64; lane++) {
         for (int r = 0; r < 8; r++) {
@@ -165,6 +166,27 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
     for (int b = 0; b < kNumBands; b++) {
         int n = (int)(t.band_slot0[b + 1] - t.band_slot0[b]);
         if (n > t.max_band_slots) t.max_band_slots = n;
+    }
+    // pack rows 24..26: per-lane band bookkeeping, stored as raw 32-bit patterns
+    auto PU = [&](int row, int lane, int i, uint32_t v) { memcpy(&t.pack[((size_t)row * 64 + lane) * 4 + i], &v, 4); };
+    for (int lane = 0; lane < 64; lane++) {
+        for (int i = 0; i < 8; i++) {
+            uint32_t b0 = t.band[16 * lane + 2 * i], b1 = t.band[16 * lane + 2 * i + 1];
+            PU(24 + i / 4, lane, i % 4, (b0 * 8u) | ((b1 * 8u) << 16));  // byte offsets into bandv (float2 per band)
+        }
+        const int bl = lane & 31;
+        const int b = bl < 25 ? bl : 24;
+        const float cnt = t.band_count[b];
+        const float rcount = cnt > 0.f ? 1.0f / cnt : 0.f;
+        uint32_t rc;
+        memcpy(&rc, &rcount, 4);
+        // band b is reduced by lane b (even slots) and lane 32 + b (odd slots)
+        const uint32_t bs0 = t.band_slot0[b] + (uint32_t)(lane >> 5);
+        const uint32_t bs1 = bl < 25 ? t.band_slot0[b + 1] : 0u;
+        PU(26, lane, 0, t.lane_bnd[lane]);
+        PU(26, lane, 1, t.lane_slot0[lane]);
+        PU(26, lane, 2, rc);
+        PU(26, lane, 3, bs0 | (bs1 << 16));
     }
 }
 
