@@ -239,6 +239,12 @@ class Batch:
         self.ctx._chk(self._L.flo_batch_fetch(self._h, clip, metadata, len(metadata), C.byref(out), C.byref(n)))
         return self.ctx._take(out, n)
 
+    def pack_streams(self, dst_ptr: int, dst_cap: int):
+        """Pack all DATA chunks into caller-owned device memory; returns the n_clips + 1 offsets."""
+        offs = (C.c_uint64 * (self.n_clips + 1))()
+        self.ctx._chk(self._L.flo_batch_pack_streams(self._h, dst_ptr, dst_cap, offs))
+        return list(offs)
+
     def device_streams(self):
         base = C.c_void_p()
         offs, sizes = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()

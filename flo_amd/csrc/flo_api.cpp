@@ -263,6 +263,7 @@ struct flo_batch {
     short *d_dbg_q = nullptr;
     unsigned short *d_dbg_sfw = nullptr;
     const float *d_in_coeffs = nullptr;
+    uint64_t *d_pack_plan = nullptr;
     int exact = 0;
     // results (host, valid after sync)
     bool encoded = false, synced = false;
@@ -279,7 +280,7 @@ extern "C" void flo_batch_destroy(flo_batch *b) {
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
     void *ptrs[] = {b->d_pcm, b->d_plan, b->d_hops, b->d_out, b->d_frame_size, b->d_clip_bytes, b->d_at,
-                    b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw};
+                    b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw, b->d_pack_plan};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (b->ll) lossless_plan_destroy(b->ll);
@@ -431,6 +432,8 @@ static LossyArgs make_args(flo_batch *b) {
     A.nch = b->ch;
     A.n_clips = (int)b->n_clips;
     A.total_frames = b->total_frames;
+    A.max_hops = 0;
+    for (auto h : b->hops) A.max_hops = h > A.max_hops ? h : A.max_hops;
     A.out = b->d_out;
     A.frame_size = b->d_frame_size;
     A.clip_bytes = (unsigned long long *)b->d_clip_bytes;
@@ -530,6 +533,40 @@ extern "C" int flo_batch_device_streams(flo_batch *b, const uint8_t **base, cons
         return FLO_OK;
     }
     return lossless_device_streams(b->ll, base, offsets, sizes) == 0 ? FLO_OK : FLO_ERR_STATE;
+}
+
+// Pack every clip's DATA chunk into dst (device memory owned by the caller, e.g. a torch tensor), clip i at
+// offsets[i] (16-byte aligned, offsets[n_clips] = total). Asynchronous on the ctx stream.
+extern "C" int flo_batch_pack_streams(flo_batch *b, void *dst_device, size_t dst_cap, uint64_t *offsets) {
+    if (!b || !offsets || (!dst_device && dst_cap)) return FLO_ERR_ARG;
+    flo_ctx *c = b->ctx;
+    if (!b->synced) return fail(c, FLO_ERR_STATE, "call flo_batch_encode + flo_batch_sync first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint8_t *base;
+    const uint64_t *offs, *sizes;
+    int rc = flo_batch_device_streams(b, &base, &offs, &sizes);
+    if (rc != FLO_OK) return rc;
+    uint64_t pos = 0;
+    for (size_t i = 0; i < b->n_clips; i++) {
+        offsets[i] = pos;
+        pos += (sizes[i] + 15) & ~(uint64_t)15;
+    }
+    offsets[b->n_clips] = pos;
+    if (pos > dst_cap) return fail(c, FLO_ERR_ARG, "packed stream buffer too small");
+    if (!b->n_clips || !pos) return FLO_OK;
+    if (!b->d_pack_plan) HIPCHK(c, hipMalloc(&b->d_pack_plan, 3 * b->n_clips * 8));
+    std::vector<uint64_t> plan(3 * b->n_clips);
+    for (size_t i = 0; i < b->n_clips; i++) {
+        plan[i] = offs[i];
+        plan[b->n_clips + i] = offsets[i];
+        plan[2 * b->n_clips + i] = sizes[i];
+    }
+    HIPCHK(c, hipMemcpyAsync(b->d_pack_plan, plan.data(), plan.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // plan is a stack-lifetime host buffer
+    const unsigned long long *dp = (const unsigned long long *)b->d_pack_plan;
+    return timed_launch(c, "pack_streams", [&] {
+        return launch_pack_streams(base, dp, dp + b->n_clips, dp + 2 * b->n_clips, (int)b->n_clips, (uint8_t *)dst_device, c->stream);
+    });
 }
 
 extern "C" int flo_batch_fetch(flo_batch *b, size_t clip, const uint8_t *meta, size_t meta_len, uint8_t **out,

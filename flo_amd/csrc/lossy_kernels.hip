@@ -379,20 +379,28 @@ __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
     for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
 }
 
-// temporal recurrence s_t = max(a_t, 0.7 s_{t-1}), s_{-1} = 0 (psychoacoustic.rs:198-203): one thread per
-// (clip, channel, band) walks the clip's frames; writes the state seen BEFORE each frame.
+// temporal recurrence s_t = max(a_t, 0.7 s_{t-1}), s_{-1} = 0 (psychoacoustic.rs:198-203) for the frame-parallel
+// form: blocks of 64 frames, one thread per (clip, block, channel, band), each warmed up over the 64 frames before its
+// block. History older than 64 frames can only contribute 0.7^64 (1e-10) of its level; levels below 4.77e-7 (half an
+// ulp of 10) vanish in fl(s - 10) and in max(s, ath) - 10, so every threshold derived from the blocked scan is
+// bit-identical to the sequential chain's (the chain kernel keeps the true sequential state).
+// Writes the state seen BEFORE each frame.
+constexpr int kScanBlock = 64;
 __global__ void lossy_scan_kernel(LossyArgs A) {
-    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned per_clip = (unsigned)A.nch * 32u;
-    const unsigned clip = t / per_clip;
+    const unsigned clip = blockIdx.y;
     if (clip >= (unsigned)A.n_clips) return;
-    const unsigned rem = t % per_clip;
-    const unsigned ch = rem >> 5, band = rem & 31u;
-    if (band >= 25) return;
-    const unsigned long long f0 = A.clip_frame0[clip];
     const unsigned hops = A.clip_hops[clip];
+    const unsigned blk = blockIdx.x;
+    const unsigned fs = blk * kScanBlock;
+    if (fs >= hops) return;
+    const unsigned ch = threadIdx.x >> 5, band = threadIdx.x & 31u;
+    if (ch >= (unsigned)A.nch || band >= 25) return;
+    const unsigned long long f0 = A.clip_frame0[clip];
+    const unsigned fw = fs >= kScanBlock ? fs - kScanBlock : 0;
+    const unsigned fe = fs + kScanBlock < hops ? fs + kScanBlock : hops;
     float s = 0.f;
-    for (unsigned h = 0; h < hops; h++) {
+    for (unsigned h = fw; h < fs; h++) s = fmaxf(A.a_t[((f0 + h) * A.nch + ch) * 32 + band], s * 0.7f);
+    for (unsigned h = fs; h < fe; h++) {
         const unsigned long long idx = ((f0 + h) * A.nch + ch) * 32 + band;
         A.s_prev_out[idx] = s;
         s = fmaxf(A.a_t[idx], s * 0.7f);
@@ -416,18 +424,30 @@ __global__ void lossy_compact_kernel(LossyArgs A) {
     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
 }
 
-// exclusive scan of frame sizes inside each clip (one thread per clip; clips here are few and long)
-__global__ void lossy_frame_offsets_kernel(LossyArgs A) {
-    const unsigned clip = blockIdx.x * blockDim.x + threadIdx.x;
+// exclusive scan of frame sizes inside each clip: one workgroup per clip, 256 frames per pass with a running carry
+__global__ __launch_bounds__(256) void lossy_frame_offsets_kernel(LossyArgs A) {
+    __shared__ unsigned long long sc[256];
+    const unsigned clip = blockIdx.x;
     if (clip >= (unsigned)A.n_clips) return;
     const unsigned long long f0 = A.clip_frame0[clip];
     const unsigned hops = A.clip_hops[clip];
-    unsigned long long off = 0;
-    for (unsigned h = 0; h < hops; h++) {
-        A.frame_off[f0 + h] = off;
-        off += A.frame_size[f0 + h];
+    unsigned long long carry = 0;
+    for (unsigned base = 0; base < hops; base += 256) {
+        const unsigned h = base + threadIdx.x;
+        const unsigned long long v = h < hops ? A.frame_size[f0 + h] : 0;
+        sc[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            unsigned long long t = threadIdx.x >= (unsigned)d ? sc[threadIdx.x - d] : 0;
+            __syncthreads();
+            sc[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (h < hops) A.frame_off[f0 + h] = carry + sc[threadIdx.x] - v;
+        carry += sc[255];
+        __syncthreads();
     }
-    A.clip_bytes[clip] = off;
+    if (threadIdx.x == 0) A.clip_bytes[clip] = carry;
 }
 
 // ---------------------------------------------------------------------------------------------- stage kernels
@@ -465,6 +485,20 @@ __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigne
     wave_sync();
     for (uint32_t i = lane; i < P.total; i += 64) slots[w * 2080 + i] = stage[i];
     if (lane == 0) sizes[w] = P.total;
+}
+
+// Copy every clip's DATA chunk into one caller-provided buffer, back to back at 16-byte aligned offsets (the packed
+// form handed to the RCCL gather). 16-byte units: sources are 16-byte aligned by construction.
+__global__ void pack_streams_kernel(const uint8_t *src, const unsigned long long *src_off, const unsigned long long *dst_off,
+                                    const unsigned long long *sizes, int n_clips, uint8_t *dst) {
+    const int clip = blockIdx.y;
+    if (clip >= n_clips) return;
+    const unsigned long long n16 = (sizes[clip] + 15) >> 4;
+    const uint4 *s = reinterpret_cast<const uint4 *>(src + src_off[clip]);
+    uint4 *d = reinterpret_cast<uint4 *>(dst + dst_off[clip]);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        d[i] = s[i];
 }
 
 // integer-exact synthetic PCM (include/flo_synth.h), one thread per 4 interleaved samples
@@ -535,13 +569,13 @@ int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s) {
     return 0;
 }
 int launch_lossy_scan(const LossyArgs &A, hipStream_t s) {
-    unsigned threads = (unsigned)A.n_clips * (unsigned)A.nch * 32u;
-    hipLaunchKernelGGL(lossy_scan_kernel, dim3((threads + 63) / 64), dim3(64), 0, s, A);
+    unsigned max_hops = (unsigned)A.max_hops;
+    hipLaunchKernelGGL(lossy_scan_kernel, dim3((max_hops + kScanBlock - 1) / kScanBlock, A.n_clips), dim3(32 * A.nch), 0, s, A);
     FLO_LAUNCH_CHECK();
     return 0;
 }
 int launch_lossy_compact(const LossyArgs &A, hipStream_t s) {
-    hipLaunchKernelGGL(lossy_frame_offsets_kernel, dim3((A.n_clips + 63) / 64), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(lossy_frame_offsets_kernel, dim3(A.n_clips), dim3(256), 0, s, A);
     FLO_LAUNCH_CHECK();
     hipLaunchKernelGGL(lossy_compact_kernel, dim3((unsigned)A.total_frames), dim3(256), 0, s, A);
     FLO_LAUNCH_CHECK();
@@ -554,6 +588,12 @@ int launch_mdct_only(const LossyDevTables &T, const float *frames, unsigned long
 }
 int launch_sparse_only(const short *q, unsigned long long n, uint8_t *slots, uint32_t *sizes, hipStream_t s) {
     hipLaunchKernelGGL(sparse_only_kernel, dim3((unsigned)n), dim3(64), 0, s, q, n, slots, sizes);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_pack_streams(const uint8_t *src, const unsigned long long *src_off, const unsigned long long *dst_off,
+                        const unsigned long long *sizes, int n_clips, uint8_t *dst, hipStream_t s) {
+    hipLaunchKernelGGL(pack_streams_kernel, dim3(8, n_clips), dim3(256), 0, s, src, src_off, dst_off, sizes, n_clips, dst);
     FLO_LAUNCH_CHECK();
     return 0;
 }

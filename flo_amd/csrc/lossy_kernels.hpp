@@ -18,6 +18,7 @@ struct LossyArgs {
     int nch;
     int n_clips;
     unsigned long long total_frames;
+    unsigned int max_hops;                   // longest clip, in frames
     // output
     uint8_t *out;                            // DATA chunks
     const unsigned long long *out_off;       // [n_clips] byte offset of the clip's DATA chunk (16-byte aligned)
@@ -43,6 +44,8 @@ int launch_lossy_scan(const LossyArgs &A, hipStream_t s);
 int launch_lossy_compact(const LossyArgs &A, hipStream_t s);
 int launch_mdct_only(const LossyDevTables &T, const float *frames, unsigned long long n, float *out, hipStream_t s);
 int launch_sparse_only(const short *q, unsigned long long n, uint8_t *slots, uint32_t *sizes, hipStream_t s);
+int launch_pack_streams(const uint8_t *src, const unsigned long long *src_off, const unsigned long long *dst_off,
+                        const unsigned long long *sizes, int n_clips, uint8_t *dst, hipStream_t s);
 int launch_synth_fill(float *pcm, const unsigned long long *clip_off, const unsigned long long *clip_nsf, int n_clips,
                       int nch, uint32_t seed, unsigned long long clip_id0, hipStream_t s);
 

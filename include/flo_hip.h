@@ -91,6 +91,10 @@ int flo_batch_fetch(flo_batch *b, size_t clip, const uint8_t *meta, size_t meta_
  * clip i's DATA chunk is at base + offsets[i], sizes[i] bytes (both arrays host-side, n_clips entries) */
 int flo_batch_device_streams(flo_batch *b, const uint8_t **base, const uint64_t **offsets, const uint64_t **sizes);
 
+/* pack every clip's DATA chunk back to back (16-byte aligned offsets) into a caller-owned device buffer on the ctx
+ * stream: the single contiguous payload a rank contributes to the RCCL gather. offsets has n_clips + 1 entries. */
+int flo_batch_pack_streams(flo_batch *b, void *dst_device, size_t dst_cap, uint64_t *offsets);
+
 /* ---- measurement hooks ----------------------------------------------------------------------------- */
 /* When enabled, every launch of a named kernel on the ctx stream is bracketed by hipEvents on that stream. */
 int flo_ctx_profile_enable(flo_ctx *ctx, int on);

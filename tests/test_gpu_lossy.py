@@ -228,3 +228,50 @@ def test_synthetic_corpus_properties_at_scale(ctx):
         compare_lossy_stage(ctx.lossy_analyze(pcm, 44100, 2, 0.55), O.lossy_analyze(pcm, 44100, 2, 0.55), 44100, f"clip{i}")
         ctx.force_path(0)
     b.close()
+
+
+def test_pack_streams_and_single_rank_rccl_gather(ctx):
+    # the exchange step of the multi-GPU path, exercised with a 1-rank "nccl" (= RCCL) group on the one GPU here
+    import os
+    import torch
+    import torch.distributed as dist
+    import flo_amd
+    from flo_amd.dist import gather_payloads
+    clips = [signals.music_like(44100, n, 2, seed=n) for n in (5000, 44100, 12345)]
+    b = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [c.size for c in clips], 44100, 2, 0.55)
+    for i, c in enumerate(clips):
+        b.upload(i, c)
+    b.encode(1)
+    b.sync()
+    buf = torch.empty(b.data_bytes() + 16 * 3 + 64, dtype=torch.uint8, device="cuda:0")
+    offs = b.pack_streams(buf.data_ptr(), buf.numel())
+    b.sync()
+    host = buf.cpu().numpy()
+    for i in range(3):
+        f = flofile.parse(b.fetch(i))
+        assert host[offs[i]:offs[i] + f.data_size].tobytes() == f.data and offs[i] % 16 == 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got, sizes = gather_payloads(dist, buf[: offs[-1]], 0, 1, 0)
+        assert sizes == [offs[-1]] and got[0].data_ptr() == buf.data_ptr()
+    finally:
+        dist.destroy_process_group()
+    b.close()
+
+
+def test_blocked_scan_matches_sequential_chain_on_long_decays(ctx):
+    # frame-parallel form uses a blocked temporal scan (64-frame warm-up); the chain kernel the true recurrence.
+    # Loud burst, then long near-silence (levels decay through hundreds of frames), then another burst.
+    sr, n = 44100, 44100 * 12
+    x = signals.fast_noise(n * 2, 4, 1e-4)
+    x[: sr] += signals.music_like(sr, sr // 2, 2, seed=2)[: sr] * 2.0
+    x[8 * sr * 2: 8 * sr * 2 + sr] += signals.music_like(sr, sr // 2, 2, seed=3)[: sr]
+    x = np.clip(x, -1, 1).astype(np.float32)
+    ctx.force_path(1)
+    a = ctx.encode_lossy(x, sr, 2, 0.55)
+    ctx.force_path(2)
+    b = ctx.encode_lossy(x, sr, 2, 0.55)
+    ctx.force_path(0)
+    assert a == b and len(flofile.parse(a).frames) == (n + 1024 + 1023) // 1024
