@@ -224,7 +224,7 @@ static int get_tables(flo_ctx *c, uint32_t sr, float quality, TableSet **out) {
     t->dev.max_band_slots = h.max_band_slots;
     t->dev.smr_thr = h.smr_threshold;
     t->dev.q_transparent = h.q_transparent;
-    if (h.n_slots > kSlotCap) {
+    if (h.n_slots > kSlotCap || h.max_band_slots > 48) {
         hipFree(t->blob);
         delete t;
         return fail(c, FLO_ERR_ARG, "band segment table exceeds capacity");
@@ -264,6 +264,7 @@ struct flo_batch {
     unsigned short *d_dbg_sfw = nullptr;
     const float *d_in_coeffs = nullptr;
     uint64_t *d_pack_plan = nullptr;
+    unsigned long long *d_stamps = nullptr;
     int exact = 0;
     // results (host, valid after sync)
     bool encoded = false, synced = false;
@@ -447,6 +448,7 @@ static LossyArgs make_args(flo_batch *b) {
     A.dbg_sfw = b->d_dbg_sfw;
     A.in_coeffs = b->d_in_coeffs;
     A.exact = b->exact;
+    A.dbg_stamps = b->d_stamps;
     return A;
 }
 
@@ -466,6 +468,9 @@ extern "C" int flo_batch_encode(flo_batch *b, int which) {
     if (which == 0) which = c->force_path;
     if (which == 0) which = (b->n_clips * b->ch >= 512) ? 1 : 2;
     if (which == 1) {
+#ifdef FLO_STAMPS
+        if (!b->d_stamps) HIPCHK(c, hipMalloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
+#endif
         LossyArgs A = make_args(b);
         return timed_launch(c, "lossy_chain", [&] { return launch_lossy_chain(A, c->stream); });
     }
@@ -501,6 +506,21 @@ extern "C" int flo_batch_sync(flo_batch *b) {
             }
             for (size_t i = 0; i < b->n_clips; i++)
                 if (b->h_clip_bytes[i] > b->out_cap[i]) return fail(c, FLO_ERR_DEVICE, "bitstream overran its buffer");
+#ifdef FLO_STAMPS
+            if (b->d_stamps) {
+                std::vector<unsigned long long> st(b->n_clips * b->ch * 16);
+                HIPCHK(c, hipMemcpy(st.data(), b->d_stamps, st.size() * 8, hipMemcpyDeviceToHost));
+                double sum[14] = {0};
+                for (size_t w = 0; w < b->n_clips * b->ch; w++)
+                    for (int i = 0; i < 14; i++) sum[i] += (double)st[w * 16 + i];
+                double frames = (double)b->total_frames * b->ch;
+                static const char *nm[] = {"wait-loads+fold", "issue-loads", "fft", "postrot", "analyse(bands,psy,quant,plan)",
+                                           "sync-tot", "emit", "sync-emit", "flush", "sync-tail"};
+                fprintf(stderr, "[stamps] s_memtime ticks (100 MHz) per frame-channel:");
+                for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%.2f", nm[i], sum[i] / frames);
+                fprintf(stderr, "\n");
+            }
+#endif
         } else {
             std::string err;
             if (lossless_collect(b->ll, err) != 0) return fail(c, FLO_ERR_DEVICE, "lossless collect: " + err);

@@ -28,7 +28,11 @@ namespace flo {
 //   rows 16..19 : FFT pass-2 twiddles W64^((lane&7) k), k = 1..7
 //   rows 20..23 : ATH amplitude thresholds of coefficients 16 lane .. 16 lane + 15
 //   rows 24..26 : per-lane band bookkeeping of the contiguous layout (see load_lane_const)
-constexpr int kPackRows = 27;
+//   rows 27..30 : byte offset into bandv of each of the lane's 16 coefficients
+//   rows 31..34 : band-statistics keep multipliers (0.0 after a band boundary, else 1.0)
+//   rows 35..38 : byte offset of the slot each running (sum, max) is stored to (segment slot or the lane's trash slot)
+//   rows 39..44 : byte offsets of the up to 24 slots this band lane adds (zero slot when exhausted)
+constexpr int kPackRows = 45;
 
 struct LossyDevTables {
     const float4 *pack;      // [kPackRows][64]
@@ -59,7 +63,7 @@ struct WaveLds {
         float coef[CH][kCoefFloats];   // transposition to the contiguous layout
         int16_t qbuf[CH][1024];        // quantised values, fetched by run-time position while emitting
     } u;
-    float2 slots[CH][kSlotCap];        // (sum c^2, max |c|) per lane segment
+    float2 slots[CH][kSlotCap + 64 + 1];  // (sum c^2, max |c|) per lane segment | 64 per-lane trash slots | one zero slot
     float2 bandv[CH][32];              // per band: (amplitude threshold, scale factor)
     float band_s[CH][32];              // per band: masking level s in dB (exact re-check only)
 };
@@ -273,21 +277,31 @@ __device__ __forceinline__ void load_half(const int lane, const float *__restric
 template <int CH>
 __device__ __forceinline__ void load_half_fast(const int lane, const float *__restrict__ pcm, int nch, int c0, long long s0,
                                                float (&he)[CH][8], float (&ho)[CH][8]) {
-    const float *base = pcm + s0 * nch + c0;
+    const float *base = pcm + s0 * nch + c0;   // wave-uniform; per-lane part stays a 32-bit offset
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         int eo, oo;
         half_offsets(lane, r, eo, oo);
         if (CH == 2) {
-            float2 a = *reinterpret_cast<const float2 *>(base + 2 * eo);
-            float2 b = *reinterpret_cast<const float2 *>(base + 2 * oo);
+            float2 a = *reinterpret_cast<const float2 *>(base + (unsigned)(2 * eo));
+            float2 b = *reinterpret_cast<const float2 *>(base + (unsigned)(2 * oo));
             he[0][r] = a.x;
             he[CH - 1][r] = a.y;
             ho[0][r] = b.x;
             ho[CH - 1][r] = b.y;
         } else {
-            he[0][r] = base[eo * nch];
-            ho[0][r] = base[oo * nch];
+#ifdef FLO_FAKE_LOADS   // diagnostic: issue only a quarter of the loads (results are wrong, timing only)
+            if (r < 2) {
+                he[0][r] = base[eo * nch];
+                ho[0][r] = base[oo * nch];
+            } else {
+                he[0][r] = he[0][r & 1];
+                ho[0][r] = ho[0][r & 1];
+            }
+#else
+            he[0][r] = base[(unsigned)(eo * nch)];
+            ho[0][r] = base[(unsigned)(oo * nch)];
+#endif
         }
     }
 }
@@ -362,55 +376,48 @@ __device__ __forceinline__ void post_rotate_transpose(const int lane, const floa
 // ------------------------------------------------------------------------------------------------ bands
 // Per-lane constants of the contiguous layout (lane j owns coefficients 16 j .. 16 j + 15)
 struct LaneConst {
-    uint32_t bnd;      // bit e: a band segment ends after element e
-    uint32_t slot0;    // first slot of this lane
-    uint32_t boff[8];  // 16 x u16: byte offset (band * 8) into bandv for element e
     float rcount;      // band lanes: 1 / bins in the band (0 for an empty band)
-    uint32_t bs0, bs1; // band lanes: slots [bs0, bs1) with stride 2 belong to this lane
 };
 // Band b is reduced by lane b (even slots of the band) and lane 32 + b (odd slots); lane b adds the two halves.
 
 __device__ __forceinline__ void load_lane_const(const int lane, LaneConst &L, const LossyDevTables &T) {
-    // pack rows 24..26 (built by tables.cpp): 8 x boff | bnd, slot0, 1/count, bs0 | bs1 << 16
-    const float4 a = T.pack[24 * 64 + lane], b = T.pack[25 * 64 + lane], c = T.pack[26 * 64 + lane];
-    L.boff[0] = __float_as_uint(a.x); L.boff[1] = __float_as_uint(a.y); L.boff[2] = __float_as_uint(a.z); L.boff[3] = __float_as_uint(a.w);
-    L.boff[4] = __float_as_uint(b.x); L.boff[5] = __float_as_uint(b.y); L.boff[6] = __float_as_uint(b.z); L.boff[7] = __float_as_uint(b.w);
-    L.bnd = __float_as_uint(c.x);
-    L.slot0 = __float_as_uint(c.y);
-    L.rcount = c.z;
-    L.bs0 = __float_as_uint(c.w) & 0xFFFFu;
-    L.bs1 = __float_as_uint(c.w) >> 16;
+    L.rcount = T.pack[26 * 64 + lane].z;
 }
 
+constexpr int kZeroSlot = kSlotCap + 64;
+
 // Band energy (sum of c^2) and band maximum |c| (psychoacoustic.rs:155-163, encoder.rs:111-118).
-// Each lane accumulates its 16 coefficients in ascending order and closes a partial at every band boundary into
-// its own LDS slot; lanes b and 32+b add the even / odd slots of band b in ascending order and lane b adds the two
-// halves: a fixed summation tree, independent of run and of grid shape. Result in lanes 0..24.
+// Each lane accumulates its 16 coefficients in ascending order; after every element the running (sum, max) is
+// stored to the lane's next segment slot when the element closes a band segment, else to the lane's trash slot
+// (destinations and the 0/1 restart multipliers come from the pack: no compares, selects or branches).
+// Lanes b and 32+b then add the even / odd slots of band b in ascending order and lane b adds the two halves:
+// a fixed summation tree, independent of run and of grid shape. Result in lanes 0..24.
 template <int CH>
-__device__ __forceinline__ void band_stats(const float (&c)[CH][16], float2 (*slots)[kSlotCap], const LaneConst &L,
-                                           int max_band_slots, float (&energy)[CH], float (&bmax)[CH]) {
+__device__ __forceinline__ void band_stats(const int lane, const float (&c)[CH][16], float2 (*slots)[kSlotCap + 64 + 1],
+                                           const LossyDevTables &T, float (&energy)[CH], float (&bmax)[CH]) {
     float acc[CH], mx[CH];
-    uint32_t slot = L.slot0;
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
         acc[ch] = 0.f;
         mx[ch] = 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
+    for (int g = 0; g < 4; g++) {
+        const float4 keep = T.pack[(31 + g) * 64 + lane];
+        const float4 dsto = T.pack[(35 + g) * 64 + lane];
+        const float kp[4] = {keep.x, keep.y, keep.z, keep.w};
+        const uint32_t dv[4] = {__float_as_uint(dsto.x), __float_as_uint(dsto.y), __float_as_uint(dsto.z), __float_as_uint(dsto.w)};
 #pragma unroll
-        for (int ch = 0; ch < CH; ch++) {
-            acc[ch] = fmaf(c[ch][e], c[ch][e], acc[ch]);
-            mx[ch] = fmaxf(mx[ch], fabsf(c[ch][e]));
-        }
-        if (L.bnd & (1u << e)) {
+        for (int u = 0; u < 4; u++) {
+            const int e = 4 * g + u;
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
-                slots[ch][slot] = make_float2(acc[ch], mx[ch]);
-                acc[ch] = 0.f;
-                mx[ch] = 0.f;
+                acc[ch] = fmaf(c[ch][e], c[ch][e], acc[ch]);
+                mx[ch] = fmaxf(mx[ch], fabsf(c[ch][e]));
+                *reinterpret_cast<float2 *>(reinterpret_cast<char *>(slots[ch]) + dv[u]) = make_float2(acc[ch], mx[ch]);
+                acc[ch] *= kp[u];
+                mx[ch] *= kp[u];
             }
-            slot++;
         }
     }
     wave_sync();
@@ -419,17 +426,24 @@ __device__ __forceinline__ void band_stats(const float (&c)[CH][16], float2 (*sl
         energy[ch] = 0.f;
         bmax[ch] = 0.f;
     }
-    const int iters = (max_band_slots + 1) >> 1;
-    for (int i = 0; i < iters; i++) {
-        const uint32_t s = L.bs0 + 2u * (uint32_t)i;
-        if (s < L.bs1) {
+    // lanes b / 32+b: even / odd slots of band b; the list is padded with the zero slot
+    const int groups = (T.max_band_slots + 7) >> 3;  // 4 list entries per group, each lane takes every other slot
+    for (int g = 0; g < groups; g++) {
+        const float4 lst = T.pack[(39 + g) * 64 + lane];
+        const uint32_t so[4] = {__float_as_uint(lst.x), __float_as_uint(lst.y), __float_as_uint(lst.z), __float_as_uint(lst.w)};
+        float2 v[CH][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int ch = 0; ch < CH; ch++)
+                v[ch][u] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(slots[ch]) + so[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
-                float2 v = slots[ch][s];
-                energy[ch] += v.x;
-                bmax[ch] = fmaxf(bmax[ch], v.y);
+                energy[ch] += v[ch][u].x;
+                bmax[ch] = fmaxf(bmax[ch], v[ch][u].y);
             }
-        }
     }
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
@@ -506,37 +520,43 @@ __device__ __forceinline__ float round_away(float x) {
 template <int CH, bool EXACT>
 __device__ __forceinline__ void quantise(const int lane, const float (&c)[CH][16], const WaveLds<CH> &lds, const LaneConst &L,
                                          const LossyDevTables &T, int (&q)[CH][16]) {
-    float al[16];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        float4 v = T.pack[(20 + i) * 64 + lane];
-        al[4 * i] = v.x;
-        al[4 * i + 1] = v.y;
-        al[4 * i + 2] = v.z;
-        al[4 * i + 3] = v.w;
-    }
+    for (int g = 0; g < 4; g++) {
+        const float4 al4 = T.pack[(20 + g) * 64 + lane];
+        const float4 bo4 = T.pack[(27 + g) * 64 + lane];
+        const float al[4] = {al4.x, al4.y, al4.z, al4.w};
+        const uint32_t bo[4] = {__float_as_uint(bo4.x), __float_as_uint(bo4.y), __float_as_uint(bo4.z), __float_as_uint(bo4.w)};
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const uint32_t off = (e & 1) ? (L.boff[e >> 1] >> 16) : (L.boff[e >> 1] & 0xFFFFu);
+        for (int u = 0; u < 4; u++) {
+            const int e = 4 * g + u;
 #pragma unroll
-        for (int ch = 0; ch < CH; ch++) {
-            const float2 bv = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lds.bandv[ch]) + off);
-            const float x = c[ch][e];
-            const float ax = fabsf(x);
-            const float thr = fmaxf(bv.x, al[e]);
-            bool keep = ax > thr;
-            if (EXACT) {
-                // |c| <= 1e-10 takes the reference's "-100 dB" branch; it can only be kept at quality >= 0.99
-                const bool near = fabsf(ax - thr) <= 1e-5f * thr || (T.q_transparent && !(ax > 1e-10f));
-                if (near) {
-                    float signal_db = ax > 1e-10f ? 20.0f * log10f(ax) : -100.0f;
-                    float sdb = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds.band_s[ch]) + (off >> 1));
-                    float t = fmaxf(sdb, T.ath_db[16 * lane + e]) - 10.0f;
-                    keep = (signal_db - t) > T.smr_thr;
+            for (int ch = 0; ch < CH; ch++) {
+                const float2 bv = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lds.bandv[ch]) + bo[u]);
+                const float x = c[ch][e];
+                const float ax = fabsf(x);
+                const float thr = fmaxf(bv.x, al[u]);
+                // round half away from zero == truncate(x + copysign(pred(0.5), x)) for every f32 (verified exhaustively
+                // on [0.25, 4) and at all half-integers); the truncating conversion saturates and maps NaN to 0
+                const float xs = x * bv.y;
+                const float half = __uint_as_float((__float_as_uint(xs) & 0x80000000u) | 0x3EFFFFFFu);
+                const int v = __float2int_rz(xs + half);
+                if (EXACT) {
+                    bool keep = ax > thr;
+                    // |c| <= 1e-10 takes the reference's "-100 dB" branch; it can only be kept at quality >= 0.99
+                    const bool near = fabsf(ax - thr) <= 1e-5f * thr || (T.q_transparent && !(ax > 1e-10f));
+                    if (near) {
+                        float signal_db = ax > 1e-10f ? 20.0f * log10f(ax) : -100.0f;
+                        float sdb = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds.band_s[ch]) + (bo[u] >> 1));
+                        float t = fmaxf(sdb, T.ath_db[16 * lane + e]) - 10.0f;
+                        keep = (signal_db - t) > T.smr_thr;
+                    }
+                    q[ch][e] = keep ? v : 0;
+                } else {
+                    // keep iff |c| > thr: all-ones mask from the sign of (thr - |c|); NaN compares false like the reference
+                    const int mask = __float_as_int(thr - ax) >> 31;
+                    q[ch][e] = v & mask;   // a NaN coefficient already gave v = 0
                 }
             }
-            const int v = __float2int_rz(round_away(x * bv.y));  // saturating; NaN -> 0
-            q[ch][e] = keep ? v : 0;
         }
     }
 }
@@ -627,7 +647,8 @@ __device__ __forceinline__ void sparse_plan(const int lane, const int (&q)[16], 
 
 // Emit this lane's part of the sparse blob to `dst` (LDS bytes; the blob starts at dst[0]). qv = this lane's 16
 // values parked in LDS (the header loop fetches nothing from it; the value loop is static).
-__device__ __forceinline__ void sparse_emit(const int lane, const int (&q)[16], const SparsePlan &P, uint8_t *dst) {
+__device__ __forceinline__ void sparse_emit(const int lane, const int (&q)[16], const SparsePlan &P, uint8_t *dst,
+                                            uint32_t trash_off) {
     const int base = 16 * lane;
     const uint32_t m = P.M & 0xFFFFu;
     // record headers
@@ -665,16 +686,15 @@ __device__ __forceinline__ void sparse_emit(const int lane, const int (&q)[16], 
             dst[off + 1] = (uint8_t)cnt;
         }
     }
-    // values
+    // values: every position stores two bytes, zeros go to the lane's private trash bytes behind the blob
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const uint32_t K = ((1u << i) - 1u) | (((2u << i) - 1u) << 16);
-        if ((m >> i) & 1u) {
-            const uint32_t off = P.off0 + 2u * (uint32_t)__builtin_popcount(P.M & K);
-            const uint32_t v = (uint32_t)q[i];
-            dst[off] = (uint8_t)v;
-            dst[off + 1] = (uint8_t)(v >> 8);
-        }
+        const uint32_t off = P.off0 + 2u * (uint32_t)__builtin_popcount(P.M & K);
+        const uint32_t o = ((m >> i) & 1u) ? off : trash_off;
+        const uint32_t v = (uint32_t)q[i];
+        dst[o] = (uint8_t)v;
+        dst[o + 1] = (uint8_t)(v >> 8);
     }
 }
 

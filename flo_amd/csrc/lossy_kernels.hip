@@ -19,6 +19,20 @@
 #define FLO_ABLATE 0
 #endif
 #define FLO_KEEP(x) asm volatile("" ::"v"(x))
+// FLO_STAMPS (diagnostic builds only): s_memtime at phase boundaries of the chain kernel, summed per wave.
+#ifdef FLO_STAMPS
+#define STAMP(i)                                                                                  \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        st_sum[i] += t_ - st_last;                                                                \
+        st_last = t_;                                                                             \
+    } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
 namespace flo {
 
@@ -36,7 +50,7 @@ __device__ __forceinline__ void analyse_frame(const int lane, float (&c)[CH][16]
                                               unsigned long long gframe, int (&q)[CH][16], uint32_t (&sfw)[CH],
                                               SparsePlan (&P)[CH]) {
     float energy[CH], bmax[CH];
-    band_stats<CH>(c, lds.slots, L, T.max_band_slots, energy, bmax);
+    band_stats<CH>(lane, c, lds.slots, T, energy, bmax);
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
         float a = spread_threshold(lane, energy[ch], L.rcount, T);
@@ -117,7 +131,8 @@ __device__ __forceinline__ uint32_t emit_frame(const int lane, uint8_t *f, int n
             uint8_t *p = f + chpos[c];
             p[0] = (uint8_t)l; p[1] = (uint8_t)(l >> 8); p[2] = (uint8_t)(l >> 16); p[3] = (uint8_t)(l >> 24);
         }
-        sparse_emit(lane, q[ch], P[ch], f + chpos[c] + 4);
+        // trash bytes: past the end of the whole frame, two per lane (the staging buffer has 128 + bytes of slack)
+        sparse_emit(lane, q[ch], P[ch], f + chpos[c] + 4, (flen - (chpos[c] + 4)) + 2u * (uint32_t)lane);
     }
     return flen;
 }
@@ -168,7 +183,7 @@ __device__ __forceinline__ void load_coeffs(const int lane, float (&c)[CH][16], 
 constexpr int kPackBytes = kPackRows * 64 * 16;
 struct ClipLds {
     WaveLds<1> wl[2];
-    __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64];
+    __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 128];
     uint32_t tot[2];
     uint32_t cnt[2];
 };
@@ -209,7 +224,9 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
         }
     }
     __syncthreads();
-    const int wv = tid >> 6;
+    // wave-uniform values are made provably uniform: the clip's pointers, sizes and the frame loop then live in
+    // SGPRs and on the scalar unit (64-bit address arithmetic and compares cost 4-cycle VALU slots otherwise)
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cl = wv / NW;                 // clip slot inside the workgroup
     const int w = NW == 1 ? 0 : wv % NW;    // channel of this wave
     const unsigned clip = blockIdx.x * (unsigned)clips_per_wg + (unsigned)cl;
@@ -217,6 +234,7 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
     ClipLds &cs = *reinterpret_cast<ClipLds *>(lds_raw + kPackBytes + (size_t)cl * sizeof(ClipLds));
     WaveLds<1> &lds = cs.wl[w];
     uint8_t *stage = cs.stage;
+    if (lane == 0) lds.slots[0][kZeroSlot] = make_float2(0.f, 0.f);
     LossyDevTables T = A.T;
     T.pack = reinterpret_cast<const float4 *>(lds_raw);
 
@@ -238,6 +256,10 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
     }
     unsigned long long written = 0;
     uint32_t pend = 0, step = 0;
+#ifdef FLO_STAMPS
+    unsigned long long st_sum[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
     for (unsigned h = 0; h < hops; h++) {
         const int ln = lane_id_opaque();
         {
@@ -252,6 +274,7 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
         } else {
             float zr[1][8], zi[1][8];
             fold<1>(ln, ae, ao, be, bo, zr, zi, T);
+            STAMP(0);
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 ae[0][r] = be[0][r];
@@ -267,8 +290,11 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
             for (int r = 0; r < 8; r++) { FLO_KEEP(zr[0][r]); FLO_KEEP(zi[0][r]); }
             continue;
 #endif
+            STAMP(1);
             fft512<1>(ln, zr, zi, lds.u.xch, T);
+            STAMP(2);
             post_rotate_transpose<1>(ln, zr, zi, lds.u.coef, c, T);
+            STAMP(3);
             store_coeffs_dbg<1>(ln, c, A, frame0 + h, w);
         }
 #if FLO_ABLATE >= 5
@@ -283,6 +309,7 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
             load_lane_const(ln, L, T);
             analyse_frame<1, false, EXACT>(ln, c, lds, L, A, T, w, st, frame0 + h, q, sfw, P);
         }
+        STAMP(4);
 #if FLO_ABLATE >= 2
         FLO_KEEP(P[0].total); FLO_KEEP(P[0].off0); FLO_KEEP(P[0].M); FLO_KEEP(sfw[0]);
         for (int e = 0; e < 16; e++) FLO_KEEP(q[0][e]);
@@ -292,6 +319,7 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
         if (NW > 1) {
             if (ln == 0) cs.tot[w] = P[0].total;
             pair_sync(cs.cnt, w, ++step);
+            STAMP(5);
             tot[0] = cs.tot[0];
             tot[1] = cs.tot[1];
         } else {
@@ -299,11 +327,13 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
             tot[1] = 0u;
         }
         const uint32_t flen = emit_frame<1>(ln, stage + pend, NW, w, tot, sfw, P, q);
+        STAMP(6);
 #if FLO_ABLATE >= 1
         FLO_KEEP(flen);
         continue;
 #endif
         if (NW > 1) pair_sync(cs.cnt, w, ++step); else wave_sync();
+        STAMP(7);
         if (ptid == 0) A.frame_size[frame0 + h] = flen;
         // flush complete 16-byte chunks, carry the rest at the front of the staging buffer
         const uint32_t have = pend + flen;
@@ -314,9 +344,15 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
         pend = have & 15u;
         const uint32_t tb = (ptid < (int)pend) ? stage[(n16 << 4) + ptid] : 0u;
         written += (unsigned long long)n16 << 4;
+        STAMP(8);
         if (NW > 1) pair_sync(cs.cnt, w, ++step); else wave_sync();
         if (ptid < (int)pend) stage[ptid] = (uint8_t)tb;
+        STAMP(9);
     }
+#ifdef FLO_STAMPS
+    if (A.dbg_stamps && lane == 0)
+        for (int i = 0; i < 14; i++) A.dbg_stamps[((unsigned long long)clip * NW + w) * 16 + i] = st_sum[i];
+#endif
     if (NW > 1) pair_sync(cs.cnt, w, ++step); else wave_sync();
     if (ptid < (int)pend) gout[written + ptid] = stage[ptid];
     if (ptid == 0) A.clip_bytes[clip] = written + pend;
@@ -327,7 +363,7 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
 template <int CH, int PASS, bool EXACT>
 __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
     __shared__ WaveLds<CH> lds;
-    __shared__ __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 128];
     const int lane = lane_id();
     const unsigned long long gframe = blockIdx.x;
     if (gframe >= A.total_frames) return;
@@ -344,6 +380,7 @@ __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
 
     LaneConst L;
     load_lane_const(lane, L, A.T);
+    if (lane < CH) lds.slots[lane][kZeroSlot] = make_float2(0.f, 0.f);
     float c[CH][16];
     if (A.in_coeffs) {
         load_coeffs<CH>(lane, c, A, gframe, 0);
@@ -472,7 +509,7 @@ __global__ __launch_bounds__(64) void mdct_only_kernel(LossyDevTables T, const f
 // serialize_sparse of independent 1024-value vectors into fixed slots (flo_sparse_pack)
 __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigned long long n, uint8_t *slots,
                                                          uint32_t *sizes) {
-    __shared__ uint8_t stage[2080];
+    __shared__ uint8_t stage[2080 + 128];
     const unsigned long long w = blockIdx.x;
     if (w >= n) return;
     const int lane = lane_id();
@@ -481,7 +518,7 @@ __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigne
     for (int e = 0; e < 16; e++) v[e] = q[w * 1024 + 16 * lane + e];
     SparsePlan P;
     sparse_plan(lane, v, P);
-    sparse_emit(lane, v, P, stage);
+    sparse_emit(lane, v, P, stage, 2080u + 2u * (uint32_t)lane);
     wave_sync();
     for (uint32_t i = lane; i < P.total; i += 64) slots[w * 2080 + i] = stage[i];
     if (lane == 0) sizes[w] = P.total;

@@ -35,6 +35,7 @@ struct LossyArgs {
     short *dbg_q;                            // [total_frames][nch][1024]
     unsigned short *dbg_sfw;                 // [total_frames][nch][25]
     const float *in_coeffs;                  // when set: skip the transform, quantise these spectra
+    unsigned long long *dbg_stamps;          // diagnostic builds (FLO_STAMPS): per-wave phase cycle sums [wave][16]
     int exact;                               // re-decide near-threshold coefficients with the reference's dB expression
 };
 

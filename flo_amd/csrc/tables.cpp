@@ -7,6 +7,8 @@
 
 namespace flo {
 
+static const int kSlotCapHost = 96;  // == kSlotCap in lossy_device.hpp
+
 static const float kPi = 3.14159265358979323846f;  // std::f32::consts::PI
 
 static const float kBarkEdges[26] = {0.0f,    100.0f,  200.0f,  300.0f,  400.0f,  510.0f,   630.0f,
@@ -106,7 +108,7 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
     }
 
     // per-lane constant pack [row][lane][4] (layout documented in lossy_device.hpp)
-    t.pack.assign(27 * 64 * 4, 0.0f);
+    t.pack.assign(45 * 64 * 4, 0.0f);
     auto P = [&](int row, int lane, int i) -> float & { return t.pack[((size_t)row * 64 + lane) * 4 + i]; };
     for (int lane = 0; lane < 64; lane++) {
         for (int r = 0; r < 8; r++) {
@@ -183,6 +185,22 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
         // band b is reduced by lane b (even slots) and lane 32 + b (odd slots)
         const uint32_t bs0 = t.band_slot0[b] + (uint32_t)(lane >> 5);
         const uint32_t bs1 = bl < 25 ? t.band_slot0[b + 1] : 0u;
+        // rows 27..30 byte offsets into bandv (float2 per band); rows 31..34 keep multipliers; rows 35..38 slot destinations
+        {
+            uint32_t slot = t.lane_slot0[lane];
+            for (int e = 0; e < 16; e++) {
+                const bool end = (t.lane_bnd[lane] >> e) & 1u;
+                PU(27 + e / 4, lane, e % 4, (uint32_t)t.band[16 * lane + e] * 8u);
+                P(31 + e / 4, lane, e % 4) = end ? 0.0f : 1.0f;
+                PU(35 + e / 4, lane, e % 4, (end ? slot : (uint32_t)(kSlotCapHost + lane)) * 8u);
+                if (end) slot++;
+            }
+        }
+        // rows 39..44: the slots this band lane adds (every other slot of its band), padded with the zero slot
+        for (int u = 0; u < 24; u++) {
+            const uint32_t sidx = bs0 + 2u * (uint32_t)u;
+            PU(39 + u / 4, lane, u % 4, (sidx < bs1 ? sidx : (uint32_t)(kSlotCapHost + 64)) * 8u);
+        }
         PU(26, lane, 0, t.lane_bnd[lane]);
         PU(26, lane, 1, t.lane_slot0[lane]);
         PU(26, lane, 2, rc);
