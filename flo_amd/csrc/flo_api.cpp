@@ -517,7 +517,8 @@ extern "C" int flo_batch_sync(flo_batch *b) {
                 static const char *nm[] = {"wait-loads+fold", "issue-loads", "fft", "postrot", "analyse(bands,psy,quant,plan)",
                                            "sync-tot", "emit", "sync-emit", "flush", "sync-tail"};
                 fprintf(stderr, "[stamps] s_memtime ticks (100 MHz) per frame-channel:");
-                for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%.2f", nm[i], sum[i] / frames);
+                for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%.0f", nm[i], sum[i] / frames);
+                fprintf(stderr, " | inside analyse: bands=%.0f psy=%.0f quantise=%.0f (plan = analyse rest)", sum[10] / frames, sum[11] / frames, sum[12] / frames);
                 fprintf(stderr, "\n");
             }
 #endif

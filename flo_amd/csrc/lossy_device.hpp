@@ -90,6 +90,26 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ------------------------------------------------------------------------------------------------ scalar helpers
+// max / |x| max without the sNaN-quieting v_max(v, v) pair the compiler adds in front of every fmaxf: the hardware
+// instruction already returns the non-NaN operand, which is all f32::max needs.
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max_abs_raw(float a, float b) {  // max(a, |b|)
+    float r;
+    asm("v_max_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// truncating float -> int conversion as ONE instruction (saturates, NaN -> 0); the C cast would add a v_trunc
+__device__ __forceinline__ int cvt_rz(float x) {
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------ cross-lane
 // DPP moves (no LDS round trip). Lanes whose source lane does not exist keep `old`.
 //   0x111..0x11F row_shr:n   0x101..0x10F row_shl:n   0x138 wave_shr:1   0x130 wave_shl:1
@@ -277,14 +297,18 @@ __device__ __forceinline__ void load_half(const int lane, const float *__restric
 template <int CH>
 __device__ __forceinline__ void load_half_fast(const int lane, const float *__restrict__ pcm, int nch, int c0, long long s0,
                                                float (&he)[CH][8], float (&ho)[CH][8]) {
-    const float *base = pcm + s0 * nch + c0;   // wave-uniform; per-lane part stays a 32-bit offset
+    // wave-uniform base (SGPR pair) + 32-bit per-lane BYTE offsets: selects global_load ... v_off, s[base] and keeps
+    // 64-bit address arithmetic off the vector ALU
+    const char *base = reinterpret_cast<const char *>(pcm + s0 * nch + c0);
+    const unsigned stride = 4u * (unsigned)nch;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         int eo, oo;
         half_offsets(lane, r, eo, oo);
+        const unsigned be = (unsigned)eo * stride, bo = (unsigned)oo * stride;
         if (CH == 2) {
-            float2 a = *reinterpret_cast<const float2 *>(base + (unsigned)(2 * eo));
-            float2 b = *reinterpret_cast<const float2 *>(base + (unsigned)(2 * oo));
+            float2 a = *reinterpret_cast<const float2 *>(base + be);
+            float2 b = *reinterpret_cast<const float2 *>(base + bo);
             he[0][r] = a.x;
             he[CH - 1][r] = a.y;
             ho[0][r] = b.x;
@@ -292,15 +316,15 @@ __device__ __forceinline__ void load_half_fast(const int lane, const float *__re
         } else {
 #ifdef FLO_FAKE_LOADS   // diagnostic: issue only a quarter of the loads (results are wrong, timing only)
             if (r < 2) {
-                he[0][r] = base[eo * nch];
-                ho[0][r] = base[oo * nch];
+                he[0][r] = *reinterpret_cast<const float *>(base + be);
+                ho[0][r] = *reinterpret_cast<const float *>(base + bo);
             } else {
                 he[0][r] = he[0][r & 1];
                 ho[0][r] = ho[0][r & 1];
             }
 #else
-            he[0][r] = base[(unsigned)(eo * nch)];
-            ho[0][r] = base[(unsigned)(oo * nch)];
+            he[0][r] = *reinterpret_cast<const float *>(base + be);
+            ho[0][r] = *reinterpret_cast<const float *>(base + bo);
 #endif
         }
     }
@@ -413,7 +437,7 @@ __device__ __forceinline__ void band_stats(const int lane, const float (&c)[CH][
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
                 acc[ch] = fmaf(c[ch][e], c[ch][e], acc[ch]);
-                mx[ch] = fmaxf(mx[ch], fabsf(c[ch][e]));
+                mx[ch] = max_abs_raw(mx[ch], c[ch][e]);
                 *reinterpret_cast<float2 *>(reinterpret_cast<char *>(slots[ch]) + dv[u]) = make_float2(acc[ch], mx[ch]);
                 acc[ch] *= kp[u];
                 mx[ch] *= kp[u];
@@ -442,13 +466,13 @@ __device__ __forceinline__ void band_stats(const int lane, const float (&c)[CH][
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
                 energy[ch] += v[ch][u].x;
-                bmax[ch] = fmaxf(bmax[ch], v[ch][u].y);
+                bmax[ch] = max_raw(bmax[ch], v[ch][u].y);
             }
     }
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
         energy[ch] += from_other_half(energy[ch]);   // lanes 0..24: even-slot half + odd-slot half
-        bmax[ch] = fmaxf(bmax[ch], from_other_half(bmax[ch]));
+        bmax[ch] = max_raw(bmax[ch], from_other_half(bmax[ch]));
     }
     wave_sync();
 }
@@ -465,12 +489,12 @@ __device__ __forceinline__ float spread_threshold(const int lane, float energy, 
     // 16 lanes by row_shl steps; row 0 then takes the maximum of bands 16..24 from lane 16.
     const float ninf = -__builtin_inff();
     float sm = band_db;
-    sm = fmaxf(sm, dpp_f<0x101>(ninf, sm));
-    sm = fmaxf(sm, dpp_f<0x102>(ninf, sm));
-    sm = fmaxf(sm, dpp_f<0x104>(ninf, sm));
-    sm = fmaxf(sm, dpp_f<0x108>(ninf, sm));
+    sm = max_raw(sm, dpp_f<0x101>(ninf, sm));
+    sm = max_raw(sm, dpp_f<0x102>(ninf, sm));
+    sm = max_raw(sm, dpp_f<0x104>(ninf, sm));
+    sm = max_raw(sm, dpp_f<0x108>(ninf, sm));
     const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 16));
-    if (lane < 16) sm = fmaxf(sm, hi);
+    if (lane < 16) sm = max_raw(sm, hi);
     // bands j < i: band_db[j] + s10d[i-j]; only deltas with band_db_max + s10d[d] > -100 can matter
     const float gmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 0));
     int dmax = 24;
@@ -478,11 +502,11 @@ __device__ __forceinline__ float spread_threshold(const int lane, float energy, 
         int d = (int)((gmax + 100.0f) * (1.0f / 24.9f)) + 1;
         dmax = d < 1 ? 1 : (d > 24 ? 24 : d);
     }
-    float m = fmaxf(-100.0f, sm);
+    float m = max_raw(-100.0f, sm);
     float cur = band_db;
     for (int d = 1; d <= dmax; d++) {
         cur = dpp_f<0x138>(ninf, cur);  // wave_shr:1 -> band_db[lane - d]
-        m = fmaxf(m, cur + T.s10d[d]);
+        m = max_raw(m, cur + T.s10d[d]);
     }
     return m + (-6.0f);
 }
@@ -534,12 +558,12 @@ __device__ __forceinline__ void quantise(const int lane, const float (&c)[CH][16
                 const float2 bv = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lds.bandv[ch]) + bo[u]);
                 const float x = c[ch][e];
                 const float ax = fabsf(x);
-                const float thr = fmaxf(bv.x, al[u]);
+                const float thr = max_raw(bv.x, al[u]);
                 // round half away from zero == truncate(x + copysign(pred(0.5), x)) for every f32 (verified exhaustively
                 // on [0.25, 4) and at all half-integers); the truncating conversion saturates and maps NaN to 0
                 const float xs = x * bv.y;
                 const float half = __uint_as_float((__float_as_uint(xs) & 0x80000000u) | 0x3EFFFFFFu);
-                const int v = __float2int_rz(xs + half);
+                const int v = cvt_rz(xs + half);
                 if (EXACT) {
                     bool keep = ax > thr;
                     // |c| <= 1e-10 takes the reference's "-100 dB" branch; it can only be kept at quality >= 0.99

@@ -44,13 +44,29 @@ struct FrameState {
 
 // Everything between the MDCT and the byte stream for CH channels held by this wave: band statistics, masking
 // level, temporal masking, scale factors, quantiser, sparse-RLE plan. ch0 = index of c[0] among the clip's channels.
+#ifdef FLO_STAMPS
+#define ASTAMP(i)                                                                                 \
+    do {                                                                                          \
+        if (stamps) {                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            unsigned long long t_;                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+            stamps[i] += t_ - stamps[15];                                                         \
+            stamps[15] = t_;                                                                      \
+        }                                                                                         \
+    } while (0)
+#else
+#define ASTAMP(i) do {} while (0)
+#endif
 template <int CH, bool BANDS_ONLY, bool EXACT>
 __device__ __forceinline__ void analyse_frame(const int lane, float (&c)[CH][16], WaveLds<CH> &lds, const LaneConst &L,
                                               const LossyArgs &A, const LossyDevTables &T, int ch0, FrameState<CH> &st,
                                               unsigned long long gframe, int (&q)[CH][16], uint32_t (&sfw)[CH],
-                                              SparsePlan (&P)[CH]) {
+                                              SparsePlan (&P)[CH], unsigned long long *stamps = nullptr) {
     float energy[CH], bmax[CH];
     band_stats<CH>(lane, c, lds.slots, T, energy, bmax);
+    ASTAMP(10);
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
         float a = spread_threshold(lane, energy[ch], L.rcount, T);
@@ -59,7 +75,7 @@ __device__ __forceinline__ void analyse_frame(const int lane, float (&c)[CH][16]
             continue;
         }
         // temporal masking (psychoacoustic.rs:196-203)
-        float s = fmaxf(a, st.prev[ch] * 0.7f);
+        float s = max_raw(a, st.prev[ch] * 0.7f);
         st.prev[ch] = s;
         const float tlin = masking_amplitude(s, T.smr_thr);
         // scale factor (encoder.rs:121-127): IEEE division, as the reference
@@ -72,11 +88,13 @@ __device__ __forceinline__ void analyse_frame(const int lane, float (&c)[CH][16]
     }
     if (BANDS_ONLY) return;
     wave_sync();
+    ASTAMP(11);
 #if FLO_ABLATE >= 4
     for (int ch = 0; ch < CH; ch++) { FLO_KEEP(sfw[ch]); for (int e = 0; e < 16; e++) q[ch][e] = 0; P[ch].total = 3; P[ch].off0 = 0; P[ch].M = 0; }
     return;
 #endif
     quantise<CH, EXACT>(lane, c, lds, L, T, q);
+    ASTAMP(12);
 #if FLO_ABLATE >= 3
     for (int ch = 0; ch < CH; ch++) { P[ch].total = 3; P[ch].off0 = 0; P[ch].M = 0; }
     return;
@@ -255,9 +273,9 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
         else load_half<1>(lane, pcm, n_sf, NW, w, 0, be, bo);
     }
     unsigned long long written = 0;
-    uint32_t pend = 0, step = 0;
+    uint32_t pend = 0, step = 0, tailb = 0;
 #ifdef FLO_STAMPS
-    unsigned long long st_sum[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
     for (unsigned h = 0; h < hops; h++) {
@@ -307,7 +325,13 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
         {
             LaneConst L;
             load_lane_const(ln, L, T);
+#ifdef FLO_STAMPS
+            st_sum[15] = st_last;
+            analyse_frame<1, false, EXACT>(ln, c, lds, L, A, T, w, st, frame0 + h, q, sfw, P, st_sum);
+            st_last = st_sum[15];
+#else
             analyse_frame<1, false, EXACT>(ln, c, lds, L, A, T, w, st, frame0 + h, q, sfw, P);
+#endif
         }
         STAMP(4);
 #if FLO_ABLATE >= 2
@@ -318,14 +342,17 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
         uint32_t tot[2];
         if (NW > 1) {
             if (ln == 0) cs.tot[w] = P[0].total;
-            pair_sync(cs.cnt, w, ++step);
+            pair_sync(cs.cnt, w, ++step);   // both plans are known; the previous frame's flush has been read out
             STAMP(5);
             tot[0] = cs.tot[0];
             tot[1] = cs.tot[1];
         } else {
+            wave_sync();
             tot[0] = P[0].total;
             tot[1] = 0u;
         }
+        // the < 16 bytes the previous frame left unflushed go back to the front of the staging buffer
+        if (ptid < (int)pend) stage[ptid] = (uint8_t)tailb;
         const uint32_t flen = emit_frame<1>(ln, stage + pend, NW, w, tot, sfw, P, q);
         STAMP(6);
 #if FLO_ABLATE >= 1
@@ -335,27 +362,23 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
         if (NW > 1) pair_sync(cs.cnt, w, ++step); else wave_sync();
         STAMP(7);
         if (ptid == 0) A.frame_size[frame0 + h] = flen;
-        // flush complete 16-byte chunks, carry the rest at the front of the staging buffer
+        // flush complete 16-byte chunks; the rest is carried in a register until the next frame's rendezvous
         const uint32_t have = pend + flen;
         const uint32_t n16 = have >> 4;
         const uint4 *src = reinterpret_cast<const uint4 *>(stage);
         uint4 *dst = reinterpret_cast<uint4 *>(gout + written);
         for (uint32_t i = ptid; i < n16; i += 64 * NW) dst[i] = src[i];
         pend = have & 15u;
-        const uint32_t tb = (ptid < (int)pend) ? stage[(n16 << 4) + ptid] : 0u;
+        tailb = (ptid < (int)pend) ? stage[(n16 << 4) + ptid] : 0u;
         written += (unsigned long long)n16 << 4;
         STAMP(8);
-        if (NW > 1) pair_sync(cs.cnt, w, ++step); else wave_sync();
-        if (ptid < (int)pend) stage[ptid] = (uint8_t)tb;
-        STAMP(9);
     }
+    if (ptid < (int)pend) gout[written + ptid] = (uint8_t)tailb;
+    if (ptid == 0) A.clip_bytes[clip] = written + pend;
 #ifdef FLO_STAMPS
     if (A.dbg_stamps && lane == 0)
         for (int i = 0; i < 14; i++) A.dbg_stamps[((unsigned long long)clip * NW + w) * 16 + i] = st_sum[i];
 #endif
-    if (NW > 1) pair_sync(cs.cnt, w, ++step); else wave_sync();
-    if (ptid < (int)pend) gout[written + ptid] = stage[ptid];
-    if (ptid == 0) A.clip_bytes[clip] = written + pend;
 }
 
 // ---------------------------------------------------------------------------------------------- frame-parallel
