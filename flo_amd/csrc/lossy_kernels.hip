@@ -278,7 +278,9 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
     unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
-    for (unsigned h = 0; h < hops; h++) {
+    // One frame. (pe, po) hold the frame's first half, (ce, co) its second half = the next frame's first half.
+    auto frame_body = [&](const unsigned h, float (&pe)[1][8], float (&po)[1][8], float (&ce)[1][8],
+                          float (&co)[1][8]) __attribute__((always_inline)) {
         const int ln = lane_id_opaque();
         {
             unsigned zero = 0;  // keep the (rarely used) global tables out of loop-invariant registers
@@ -291,22 +293,18 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
             load_coeffs<1>(ln, c, A, frame0 + h, w);
         } else {
             float zr[1][8], zi[1][8];
-            fold<1>(ln, ae, ao, be, bo, zr, zi, T);
+            fold<1>(ln, pe, po, ce, co, zr, zi, T);
             STAMP(0);
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                ae[0][r] = be[0][r];
-                ao[0][r] = bo[0][r];
-            }
-            // issue the next half-frame's loads now; they are consumed at the top of the next iteration
+            // the older half is dead after the fold: the half-frame after next is loaded into its registers now and
+            // consumed at the top of the next call, where the two register sets have swapped roles
             if (h + 1 < hops) {
                 const long long s0 = (long long)(h + 1) * 1024;
-                if (s0 + 1024 <= n_sf) load_half_fast<1>(ln, pcm, NW, w, s0, be, bo);
-                else load_half<1>(ln, pcm, n_sf, NW, w, s0, be, bo);
+                if (s0 + 1024 <= n_sf) load_half_fast<1>(ln, pcm, NW, w, s0, pe, po);
+                else load_half<1>(ln, pcm, n_sf, NW, w, s0, pe, po);
             }
 #if FLO_ABLATE >= 6
             for (int r = 0; r < 8; r++) { FLO_KEEP(zr[0][r]); FLO_KEEP(zi[0][r]); }
-            continue;
+            return;
 #endif
             STAMP(1);
             fft512<1>(ln, zr, zi, lds.u.xch, T);
@@ -317,7 +315,7 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
         }
 #if FLO_ABLATE >= 5
         for (int e = 0; e < 16; e++) FLO_KEEP(c[0][e]);
-        continue;
+        return;
 #endif
         int q[1][16];
         uint32_t sfw[1];
@@ -337,7 +335,7 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
 #if FLO_ABLATE >= 2
         FLO_KEEP(P[0].total); FLO_KEEP(P[0].off0); FLO_KEEP(P[0].M); FLO_KEEP(sfw[0]);
         for (int e = 0; e < 16; e++) FLO_KEEP(q[0][e]);
-        continue;
+        return;
 #endif
         uint32_t tot[2];
         if (NW > 1) {
@@ -357,7 +355,7 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
         STAMP(6);
 #if FLO_ABLATE >= 1
         FLO_KEEP(flen);
-        continue;
+        return;
 #endif
         if (NW > 1) pair_sync(cs.cnt, w, ++step); else wave_sync();
         STAMP(7);
@@ -372,6 +370,11 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
         tailb = (ptid < (int)pend) ? stage[(n16 << 4) + ptid] : 0u;
         written += (unsigned long long)n16 << 4;
         STAMP(8);
+    };
+    // two frames per trip so that the two half-frame register sets alternate roles without copies
+    for (unsigned h = 0; h < hops; h += 2) {
+        frame_body(h, ae, ao, be, bo);
+        if (h + 1 < hops) frame_body(h + 1, be, bo, ae, ao);
     }
     if (ptid < (int)pend) gout[written + ptid] = (uint8_t)tailb;
     if (ptid == 0) A.clip_bytes[clip] = written + pend;
