@@ -32,7 +32,8 @@ namespace flo {
 //   rows 31..34 : band-statistics keep multipliers (0.0 after a band boundary, else 1.0)
 //   rows 35..38 : byte offset of the slot each running (sum, max) is stored to (segment slot or the lane's trash slot)
 //   rows 39..44 : byte offsets of the up to 24 slots this band lane adds (zero slot when exhausted)
-constexpr int kPackRows = 45;
+//   row  45     : not per lane - floats 0..23 are s10d[1..24] (spreading level per band distance), read uniformly
+constexpr int kPackRows = 46;
 
 struct LossyDevTables {
     const float4 *pack;      // [kPackRows][64]
@@ -481,6 +482,7 @@ __device__ __forceinline__ void band_stats(const int lane, const float (&c)[CH][
 // 10 log10(e / n) is evaluated as (10 log10 2) * log2(e * (1/n)) with the hardware log2 (1 ulp): the thresholds it
 // feeds are compared at the 1e-6 level by both implementations.
 __device__ __forceinline__ float spread_threshold(const int lane, float energy, float rcount, const LossyDevTables &T) {
+    const float4 sd0 = T.pack[45 * 64], sd1 = T.pack[45 * 64 + 1];
     const bool is_band = lane < 25;
     float band_db = -100.0f;
     if (is_band && rcount > 0.f && energy > 1e-10f) band_db = 3.01029995663981195f * __builtin_amdgcn_logf(energy * rcount);
@@ -495,18 +497,29 @@ __device__ __forceinline__ float spread_threshold(const int lane, float energy, 
     sm = max_raw(sm, dpp_f<0x108>(ninf, sm));
     const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 16));
     if (lane < 16) sm = max_raw(sm, hi);
-    // bands j < i: band_db[j] + s10d[i-j]; only deltas with band_db_max + s10d[d] > -100 can matter
-    const float gmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 0));
-    int dmax = 24;
-    if (gmax < 500.f) {
-        int d = (int)((gmax + 100.0f) * (1.0f / 24.9f)) + 1;
-        dmax = d < 1 ? 1 : (d > 24 ? 24 : d);
-    }
+    // bands j < i: band_db[j] + s10d[i-j]. Deltas 1..8 always (their constants sit in pack row 45, read before the
+    // logarithm so the LDS latency is hidden); larger deltas only when band_db_max + s10d[d] can exceed -100 dB,
+    // which takes levels above 99 dB (input far outside [-1, 1]).
     float m = max_raw(-100.0f, sm);
     float cur = band_db;
-    for (int d = 1; d <= dmax; d++) {
+    const float sd[8] = {sd0.x, sd0.y, sd0.z, sd0.w, sd1.x, sd1.y, sd1.z, sd1.w};
+#pragma unroll
+    for (int d = 1; d <= 8; d++) {
         cur = dpp_f<0x138>(ninf, cur);  // wave_shr:1 -> band_db[lane - d]
-        m = max_raw(m, cur + T.s10d[d]);
+        m = max_raw(m, cur + sd[d - 1]);
+    }
+    const float gmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 0));
+    if (gmax >= 99.0f) {
+        int dmax = 24;
+        if (gmax < 500.f) {
+            int d = (int)((gmax + 100.0f) * (1.0f / 24.9f)) + 1;
+            dmax = d < 1 ? 1 : (d > 24 ? 24 : d);
+        }
+        const float *srow = reinterpret_cast<const float *>(T.pack + 45 * 64);
+        for (int d = 9; d <= dmax; d++) {
+            cur = dpp_f<0x138>(ninf, cur);
+            m = max_raw(m, cur + srow[d - 1]);
+        }
     }
     return m + (-6.0f);
 }

@@ -286,7 +286,6 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
             unsigned zero = 0;  // keep the (rarely used) global tables out of loop-invariant registers
             asm volatile("" : "+s"(zero));
             T.ath_db += zero;
-            T.s10d += zero;
         }
         float c[1][16];
         if (A.in_coeffs) {

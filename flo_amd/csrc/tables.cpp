@@ -108,8 +108,10 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
     }
 
     // per-lane constant pack [row][lane][4] (layout documented in lossy_device.hpp)
-    t.pack.assign(45 * 64 * 4, 0.0f);
+    t.pack.assign(46 * 64 * 4, 0.0f);
     auto P = [&](int row, int lane, int i) -> float & { return t.pack[((size_t)row * 64 + lane) * 4 + i]; };
+    // row 45 is not per lane: its first 24 floats are s10d[1..24], read uniformly by every lane
+    for (int d = 1; d < kNumBands; d++) P(45, (d - 1) / 4, (d - 1) % 4) = t.s10d[d];
     for (int lane = 0; lane < 64; lane++) {
         for (int r = 0; r < 8; r++) {
             int eo, oo;
