@@ -557,42 +557,53 @@ __device__ __forceinline__ float round_away(float x) {
 template <int CH, bool EXACT>
 __device__ __forceinline__ void quantise(const int lane, const float (&c)[CH][16], const WaveLds<CH> &lds, const LaneConst &L,
                                          const LossyDevTables &T, int (&q)[CH][16]) {
+    // Two LDS round trips for the whole frame: all constant rows first, then all (threshold, scale) gathers, then
+    // arithmetic only. (Left to itself the compiler interleaves them group by group: eight dependent round trips.)
+    float al[16];
+    uint32_t bo[16];
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const float4 al4 = T.pack[(20 + g) * 64 + lane];
         const float4 bo4 = T.pack[(27 + g) * 64 + lane];
-        const float al[4] = {al4.x, al4.y, al4.z, al4.w};
-        const uint32_t bo[4] = {__float_as_uint(bo4.x), __float_as_uint(bo4.y), __float_as_uint(bo4.z), __float_as_uint(bo4.w)};
+        al[4 * g + 0] = al4.x, al[4 * g + 1] = al4.y, al[4 * g + 2] = al4.z, al[4 * g + 3] = al4.w;
+        bo[4 * g + 0] = __float_as_uint(bo4.x), bo[4 * g + 1] = __float_as_uint(bo4.y);
+        bo[4 * g + 2] = __float_as_uint(bo4.z), bo[4 * g + 3] = __float_as_uint(bo4.w);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float2 bv[CH][16];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int e = 4 * g + u;
+    for (int e = 0; e < 16; e++)
 #pragma unroll
-            for (int ch = 0; ch < CH; ch++) {
-                const float2 bv = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lds.bandv[ch]) + bo[u]);
-                const float x = c[ch][e];
-                const float ax = fabsf(x);
-                const float thr = max_raw(bv.x, al[u]);
-                // round half away from zero == truncate(x + copysign(pred(0.5), x)) for every f32 (verified exhaustively
-                // on [0.25, 4) and at all half-integers); the truncating conversion saturates and maps NaN to 0
-                const float xs = x * bv.y;
-                const float half = __uint_as_float((__float_as_uint(xs) & 0x80000000u) | 0x3EFFFFFFu);
-                const int v = cvt_rz(xs + half);
-                if (EXACT) {
-                    bool keep = ax > thr;
-                    // |c| <= 1e-10 takes the reference's "-100 dB" branch; it can only be kept at quality >= 0.99
-                    const bool near = fabsf(ax - thr) <= 1e-5f * thr || (T.q_transparent && !(ax > 1e-10f));
-                    if (near) {
-                        float signal_db = ax > 1e-10f ? 20.0f * log10f(ax) : -100.0f;
-                        float sdb = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds.band_s[ch]) + (bo[u] >> 1));
-                        float t = fmaxf(sdb, T.ath_db[16 * lane + e]) - 10.0f;
-                        keep = (signal_db - t) > T.smr_thr;
-                    }
-                    q[ch][e] = keep ? v : 0;
-                } else {
-                    // keep iff |c| > thr: all-ones mask from the sign of (thr - |c|); NaN compares false like the reference
-                    const int mask = __float_as_int(thr - ax) >> 31;
-                    q[ch][e] = v & mask;   // a NaN coefficient already gave v = 0
+        for (int ch = 0; ch < CH; ch++)
+            bv[ch][e] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lds.bandv[ch]) + bo[e]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) {
+            const float x = c[ch][e];
+            const float ax = fabsf(x);
+            const float thr = max_raw(bv[ch][e].x, al[e]);
+            // round half away from zero == truncate(x + copysign(pred(0.5), x)) for every f32 (verified exhaustively
+            // on [0.25, 4) and at all half-integers); the truncating conversion saturates and maps NaN to 0
+            const float xs = x * bv[ch][e].y;
+            const float half = __uint_as_float((__float_as_uint(xs) & 0x80000000u) | 0x3EFFFFFFu);
+            const int v = cvt_rz(xs + half);
+            if (EXACT) {
+                bool keep = ax > thr;
+                // |c| <= 1e-10 takes the reference's "-100 dB" branch; it can only be kept at quality >= 0.99
+                const bool near = fabsf(ax - thr) <= 1e-5f * thr || (T.q_transparent && !(ax > 1e-10f));
+                if (near) {
+                    float signal_db = ax > 1e-10f ? 20.0f * log10f(ax) : -100.0f;
+                    float sdb = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds.band_s[ch]) + (bo[e] >> 1));
+                    float t = fmaxf(sdb, T.ath_db[16 * lane + e]) - 10.0f;
+                    keep = (signal_db - t) > T.smr_thr;
                 }
+                q[ch][e] = keep ? v : 0;
+            } else {
+                // keep iff |c| > thr: all-ones mask from the sign of (thr - |c|); NaN compares false like the reference
+                const int mask = __float_as_int(thr - ax) >> 31;
+                q[ch][e] = v & mask;   // a NaN coefficient already gave v = 0
             }
         }
     }
