@@ -420,6 +420,26 @@ constexpr int kZeroSlot = kSlotCap + 64;
 template <int CH>
 __device__ __forceinline__ void band_stats(const int lane, const float (&c)[CH][16], float2 (*slots)[kSlotCap + 64 + 1],
                                            const LossyDevTables &T, float (&energy)[CH], float (&bmax)[CH]) {
+    // LDS round trips are what this function costs, so they are batched: every constant row first, then the running
+    // sums with their slot writes, then all slot reads of the first three list groups (24 slots per band: enough for
+    // every band at 44.1 / 48 kHz), then arithmetic. Further groups (96 kHz) take the generic loop.
+    float kp[16];
+    uint32_t dv[16], so[12];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const float4 keep = T.pack[(31 + g) * 64 + lane];
+        const float4 dsto = T.pack[(35 + g) * 64 + lane];
+        kp[4 * g + 0] = keep.x, kp[4 * g + 1] = keep.y, kp[4 * g + 2] = keep.z, kp[4 * g + 3] = keep.w;
+        dv[4 * g + 0] = __float_as_uint(dsto.x), dv[4 * g + 1] = __float_as_uint(dsto.y);
+        dv[4 * g + 2] = __float_as_uint(dsto.z), dv[4 * g + 3] = __float_as_uint(dsto.w);
+    }
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const float4 lst = T.pack[(39 + g) * 64 + lane];
+        so[4 * g + 0] = __float_as_uint(lst.x), so[4 * g + 1] = __float_as_uint(lst.y);
+        so[4 * g + 2] = __float_as_uint(lst.z), so[4 * g + 3] = __float_as_uint(lst.w);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float acc[CH], mx[CH];
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
@@ -427,47 +447,53 @@ __device__ __forceinline__ void band_stats(const int lane, const float (&c)[CH][
         mx[ch] = 0.f;
     }
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const float4 keep = T.pack[(31 + g) * 64 + lane];
-        const float4 dsto = T.pack[(35 + g) * 64 + lane];
-        const float kp[4] = {keep.x, keep.y, keep.z, keep.w};
-        const uint32_t dv[4] = {__float_as_uint(dsto.x), __float_as_uint(dsto.y), __float_as_uint(dsto.z), __float_as_uint(dsto.w)};
+    for (int e = 0; e < 16; e++) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int e = 4 * g + u;
-#pragma unroll
-            for (int ch = 0; ch < CH; ch++) {
-                acc[ch] = fmaf(c[ch][e], c[ch][e], acc[ch]);
-                mx[ch] = max_abs_raw(mx[ch], c[ch][e]);
-                *reinterpret_cast<float2 *>(reinterpret_cast<char *>(slots[ch]) + dv[u]) = make_float2(acc[ch], mx[ch]);
-                acc[ch] *= kp[u];
-                mx[ch] *= kp[u];
-            }
+        for (int ch = 0; ch < CH; ch++) {
+            acc[ch] = fmaf(c[ch][e], c[ch][e], acc[ch]);
+            mx[ch] = max_abs_raw(mx[ch], c[ch][e]);
+            *reinterpret_cast<float2 *>(reinterpret_cast<char *>(slots[ch]) + dv[e]) = make_float2(acc[ch], mx[ch]);
+            acc[ch] *= kp[e];
+            mx[ch] *= kp[e];
         }
     }
     wave_sync();
+    // lanes b / 32+b: even / odd slots of band b in ascending order; the list is padded with the zero slot
+    float2 v[CH][12];
+#pragma unroll
+    for (int u = 0; u < 12; u++)
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++)
+            v[ch][u] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(slots[ch]) + so[u]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
         energy[ch] = 0.f;
         bmax[ch] = 0.f;
     }
-    // lanes b / 32+b: even / odd slots of band b; the list is padded with the zero slot
+#pragma unroll
+    for (int u = 0; u < 12; u++)
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) {
+            energy[ch] += v[ch][u].x;
+            bmax[ch] = max_raw(bmax[ch], v[ch][u].y);
+        }
     const int groups = (T.max_band_slots + 7) >> 3;  // 4 list entries per group, each lane takes every other slot
-    for (int g = 0; g < groups; g++) {
+    for (int g = 3; g < groups; g++) {
         const float4 lst = T.pack[(39 + g) * 64 + lane];
-        const uint32_t so[4] = {__float_as_uint(lst.x), __float_as_uint(lst.y), __float_as_uint(lst.z), __float_as_uint(lst.w)};
-        float2 v[CH][4];
+        const uint32_t sx[4] = {__float_as_uint(lst.x), __float_as_uint(lst.y), __float_as_uint(lst.z), __float_as_uint(lst.w)};
+        float2 vx[CH][4];
 #pragma unroll
         for (int u = 0; u < 4; u++)
 #pragma unroll
             for (int ch = 0; ch < CH; ch++)
-                v[ch][u] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(slots[ch]) + so[u]);
+                vx[ch][u] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(slots[ch]) + sx[u]);
 #pragma unroll
         for (int u = 0; u < 4; u++)
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
-                energy[ch] += v[ch][u].x;
-                bmax[ch] = max_raw(bmax[ch], v[ch][u].y);
+                energy[ch] += vx[ch][u].x;
+                bmax[ch] = max_raw(bmax[ch], vx[ch][u].y);
             }
     }
 #pragma unroll
@@ -701,40 +727,33 @@ __device__ __forceinline__ void sparse_emit(const int lane, const int (&q)[16], 
     const uint32_t m = P.M & 0xFFFFu;
     // record headers
     uint32_t hm = P.M >> 16;
+#ifdef FLO_EMIT_NOHDR
+    hm = 0;
+#endif
+    // One record per trip, branch-free: the trip count is the largest number of records any lane starts.
+    const int nn_rel = P.nn - base, nzend_rel = P.nz_end - base;
     while (hm) {
         const int s = __builtin_ctz(hm);
         hm &= hm - 1;
         const uint32_t below = (1u << s) - 1u;
-        uint32_t off = P.off0 + 2u * (uint32_t)__builtin_popcount(P.M & (below | (below << 16)));
-        const uint32_t above = m >> s;  // bit 0 = position s
-        uint32_t zc = 0, cnt;
-        int e;  // local position where the record's non-zero run starts
-        if (above & 1u) {
-            e = s;  // continuation / start record: [0][n]
-        } else if (above) {
-            e = s + __builtin_ctz(above);
-            zc = (uint32_t)(e - s);
-        } else {
-            e = 16;  // the zero run leaves the lane
-            zc = (uint32_t)(P.nn - (base + s));
-        }
-        if (e < 16) {
-            const int run = __builtin_ctz(~(m >> e));
-            const int len = (e + run >= 16) ? P.nz_end - (base + e) : run;
-            cnt = (uint32_t)(len < 255 ? len : 255);
-        } else {
-            cnt = P.cross_cnt;
-        }
-        if (zc >= 128u) {
-            dst[off] = (uint8_t)((zc & 0x7Fu) | 0x80u);
-            dst[off + 1] = (uint8_t)(zc >> 7);
-            dst[off + 2] = (uint8_t)cnt;
-        } else {
-            dst[off] = (uint8_t)zc;
-            dst[off + 1] = (uint8_t)cnt;
-        }
+        const uint32_t off = P.off0 + 2u * (uint32_t)__builtin_popcount(P.M & (below | (below << 16)));
+        const uint32_t above = m >> s;                      // bit 0 = position s
+        const bool leaves = above == 0u;                    // the zero run leaves the lane
+        const int zin = (int)__builtin_ctz(above | 0x10000u);   // zeros before the record's non-zero run (0 for [0][n])
+        const uint32_t zc = leaves ? (uint32_t)(nn_rel - s) : (uint32_t)zin;
+        const int e = s + zin;                              // local start of the non-zero run (>= 16 if it leaves)
+        const int run = __builtin_ctz(~(m >> (e & 15)));    // m has 16 bits: always ends by position 16
+        const int len = (e + run >= 16) ? nzend_rel - e : run;
+        uint32_t cnt = (uint32_t)(len < 255 ? len : 255);
+        cnt = leaves ? P.cross_cnt : cnt;
+        // zc >= 128 (two varint bytes) only happens when the run leaves the lane
+        const bool wide = zc >= 128u;
+        dst[off] = (uint8_t)(wide ? ((zc & 0x7Fu) | 0x80u) : zc);
+        dst[off + 1] = (uint8_t)(wide ? (zc >> 7) : cnt);
+        dst[wide ? off + 2 : trash_off] = (uint8_t)cnt;
     }
     // values: every position stores two bytes, zeros go to the lane's private trash bytes behind the blob
+#ifndef FLO_EMIT_NOVAL
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const uint32_t K = ((1u << i) - 1u) | (((2u << i) - 1u) << 16);
@@ -744,6 +763,7 @@ __device__ __forceinline__ void sparse_emit(const int lane, const int (&q)[16], 
         dst[o] = (uint8_t)v;
         dst[o + 1] = (uint8_t)(v >> 8);
     }
+#endif
 }
 
 }  // namespace flo
