@@ -111,6 +111,16 @@ __device__ __forceinline__ int cvt_rz(float x) {
     return r;
 }
 
+// Byte store into LDS as its own instruction. The frame bytes sit at arbitrary alignment; left to the optimiser, two
+// neighbouring byte stores can be merged into one misaligned 16-bit store, which gfx950 executes correctly but far
+// slower than two byte stores (measured on the value stores: chain kernel 3.1 ms -> 5.0 ms). p must point into LDS
+// (the low half of a generic LDS address is the LDS offset).
+template <int OFF = 0>
+__device__ __forceinline__ void lds_st8(uint8_t *p, uint32_t v) {
+    const uint32_t a = (uint32_t)(uintptr_t)p;
+    asm volatile("ds_write_b8 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF) : "memory");
+}
+
 // ------------------------------------------------------------------------------------------------ cross-lane
 // DPP moves (no LDS round trip). Lanes whose source lane does not exist keep `old`.
 //   0x111..0x11F row_shr:n   0x101..0x10F row_shl:n   0x138 wave_shr:1   0x130 wave_shl:1

@@ -141,8 +141,9 @@ __device__ __forceinline__ uint32_t emit_frame(const int lane, uint8_t *f, int n
     for (int ch = 0; ch < CH; ch++) {
         const int c = ch0 + ch;
         if (lane < 25) {
-            f[12 + 50 * c + 2 * lane] = (uint8_t)sfw[ch];
-            f[12 + 50 * c + 2 * lane + 1] = (uint8_t)(sfw[ch] >> 8);
+            uint8_t *p = f + 12 + 50 * c + 2 * lane;
+            lds_st8<0>(p, sfw[ch]);
+            lds_st8<1>(p, sfw[ch] >> 8);
         }
         if (lane == 32) {
             const uint32_t l = tot[c];
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(64) void mdct_only_kernel(LossyDevTables T, const f
 // serialize_sparse of independent 1024-value vectors into fixed slots (flo_sparse_pack)
 __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigned long long n, uint8_t *slots,
                                                          uint32_t *sizes) {
-    __shared__ uint8_t stage[2080 + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[2080 + 128];
     const unsigned long long w = blockIdx.x;
     if (w >= n) return;
     const int lane = lane_id();
