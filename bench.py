@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=1250)
     ap.add_argument("--clip-seconds", type=float, default=10.0)
     ap.add_argument("--quality", type=float, default=0.55)
-    ap.add_argument("--path", type=int, default=1, help="1 chain kernel, 2 frame-parallel kernels, 0 auto")
+    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 two-wave chain kernel, 2 frame-parallel kernels, 3 three-wave chain kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-clip", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=200)
@@ -93,8 +93,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    kname = "lossy_chain" if args.path in (0, 1) else "lossy_frames"
-    k_ms, k_n = ctx.profile_query(kname)
+    # the dominant kernel is whichever chain form ran (auto picks the three-wave pipeline for stereo batches)
+    kname, k_ms, k_n = "lossy_frames", 0.0, 0
+    for cand in ("lossy_chain3", "lossy_chain", "lossy_frames"):
+        ms, n = ctx.profile_query(cand)
+        if n:
+            kname, k_ms, k_n = cand, ms, n
+            break
     data_bytes = batch.data_bytes()
 
     if rank != 0:
@@ -122,7 +127,7 @@ def main():
             "workload": f"{args.clips_per_gpu} x {args.clip_seconds:g} s 44.1 kHz stereo clips per GPU, lossy quality=high "
                         f"(0.55): per-GPU shard of BASELINE configs[3] (10 000 clips / 8 GPUs)",
             "clips_per_gpu": args.clips_per_gpu, "clip_seconds": args.clip_seconds, "quality": args.quality,
-            "kernel_form": {0: "auto", 1: "chain", 2: "frame-parallel"}[args.path],
+            "kernel_form": {"lossy_chain3": "chain, three waves per stereo clip", "lossy_chain": "chain, one wave per channel", "lossy_frames": "frame-parallel"}[kname],
             "compressed_bytes_per_gpu": data_bytes,
         },
     }

@@ -115,7 +115,7 @@ extern "C" int flo_ctx_device_info(const flo_ctx *c, char *name, size_t cap, int
 }
 extern "C" void *flo_ctx_stream(flo_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int flo_ctx_force_path(flo_ctx *c, int which) {
-    if (!c || which < 0 || which > 2) return FLO_ERR_ARG;
+    if (!c || which < 0 || which > 3) return FLO_ERR_ARG;
     c->force_path = which;
     return FLO_OK;
 }
@@ -466,13 +466,18 @@ extern "C" int flo_batch_encode(flo_batch *b, int which) {
     }
     if (!b->total_frames) return FLO_OK;
     if (which == 0) which = c->force_path;
-    if (which == 0) which = (b->n_clips * b->ch >= 512) ? 1 : 2;
+    if (which == 0) which = (b->n_clips * b->ch >= 512) ? (b->ch == 2 ? 3 : 1) : 2;
     if (which == 1) {
 #ifdef FLO_STAMPS
         if (!b->d_stamps) HIPCHK(c, hipMalloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
 #endif
         LossyArgs A = make_args(b);
         return timed_launch(c, "lossy_chain", [&] { return launch_lossy_chain(A, c->stream); });
+    }
+    if (which == 3) {   // stereo pipeline: two channel waves + one packer wave per clip
+        LossyArgs A = make_args(b);
+        if (b->ch != 2) return timed_launch(c, "lossy_chain", [&] { return launch_lossy_chain(A, c->stream); });
+        return timed_launch(c, "lossy_chain3", [&] { return launch_lossy_chain3(A, c->stream); });
     }
     // frame-parallel form
     if (!b->d_at) {

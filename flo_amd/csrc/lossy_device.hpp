@@ -729,51 +729,81 @@ __device__ __forceinline__ void sparse_plan(const int lane, const int (&q)[16], 
     P.total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 }
 
-// Emit this lane's part of the sparse blob to `dst` (LDS bytes; the blob starts at dst[0]). qv = this lane's 16
-// values parked in LDS (the header loop fetches nothing from it; the value loop is static).
-__device__ __forceinline__ void sparse_emit(const int lane, const int (&q)[16], const SparsePlan &P, uint8_t *dst,
-                                            uint32_t trash_off) {
+// Emit this lane's part of the sparse blobs of CH channels (LDS bytes; blob c starts at dst[c][0]). Zero values and
+// the unused third header byte go to the lane's two private trash bytes of that channel (dst[c] + trash_off[c]).
+// With CH = 2 the two channels' record loops run merged (one trip handles one record of each) and so do the value
+// stores: two independent instruction streams for the price of the longer one.
+template <int CH>
+__device__ __forceinline__ void sparse_emit_n(const int lane, const int (&q)[CH][16], const SparsePlan (&P)[CH],
+                                              uint8_t *const (&dst)[CH], const uint32_t (&trash_off)[CH]) {
     const int base = 16 * lane;
-    const uint32_t m = P.M & 0xFFFFu;
-    // record headers
-    uint32_t hm = P.M >> 16;
+    uint32_t m[CH], hm[CH];
+    int nn_rel[CH], nzend_rel[CH];
+    uint32_t any = 0;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        m[c] = P[c].M & 0xFFFFu;
+        hm[c] = P[c].M >> 16;
 #ifdef FLO_EMIT_NOHDR
-    hm = 0;
+        hm[c] = 0;
 #endif
-    // One record per trip, branch-free: the trip count is the largest number of records any lane starts.
-    const int nn_rel = P.nn - base, nzend_rel = P.nz_end - base;
-    while (hm) {
-        const int s = __builtin_ctz(hm);
-        hm &= hm - 1;
-        const uint32_t below = (1u << s) - 1u;
-        const uint32_t off = P.off0 + 2u * (uint32_t)__builtin_popcount(P.M & (below | (below << 16)));
-        const uint32_t above = m >> s;                      // bit 0 = position s
-        const bool leaves = above == 0u;                    // the zero run leaves the lane
-        const int zin = (int)__builtin_ctz(above | 0x10000u);   // zeros before the record's non-zero run (0 for [0][n])
-        const uint32_t zc = leaves ? (uint32_t)(nn_rel - s) : (uint32_t)zin;
-        const int e = s + zin;                              // local start of the non-zero run (>= 16 if it leaves)
-        const int run = __builtin_ctz(~(m >> (e & 15)));    // m has 16 bits: always ends by position 16
-        const int len = (e + run >= 16) ? nzend_rel - e : run;
-        uint32_t cnt = (uint32_t)(len < 255 ? len : 255);
-        cnt = leaves ? P.cross_cnt : cnt;
-        // zc >= 128 (two varint bytes) only happens when the run leaves the lane
-        const bool wide = zc >= 128u;
-        dst[off] = (uint8_t)(wide ? ((zc & 0x7Fu) | 0x80u) : zc);
-        dst[off + 1] = (uint8_t)(wide ? (zc >> 7) : cnt);
-        dst[wide ? off + 2 : trash_off] = (uint8_t)cnt;
+        nn_rel[c] = P[c].nn - base;
+        nzend_rel[c] = P[c].nz_end - base;
+        any |= hm[c];
     }
-    // values: every position stores two bytes, zeros go to the lane's private trash bytes behind the blob
+    // One record (per channel) per trip, branch-free: the trip count is the largest number of records any lane starts.
+    while (any) {
+        any = 0;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const bool active = CH == 1 || hm[c] != 0u;
+            const int s = __builtin_ctz(hm[c] | 0x10000u);
+            hm[c] &= hm[c] - 1;
+            any |= hm[c];
+            const uint32_t below = (1u << s) - 1u;
+            const uint32_t off = P[c].off0 + 2u * (uint32_t)__builtin_popcount(P[c].M & (below | (below << 16)));
+            const uint32_t above = m[c] >> s;                   // bit 0 = position s
+            const bool leaves = above == 0u;                    // the zero run leaves the lane
+            const int zin = (int)__builtin_ctz(above | 0x10000u);   // zeros before the record's non-zero run (0 for [0][n])
+            const uint32_t zc = leaves ? (uint32_t)(nn_rel[c] - s) : (uint32_t)zin;
+            const int e = s + zin;                              // local start of the non-zero run (>= 16 if it leaves)
+            const int run = __builtin_ctz(~(m[c] >> (e & 15)));  // m has 16 bits: always ends by position 16
+            const int len = (e + run >= 16) ? nzend_rel[c] - e : run;
+            uint32_t cnt = (uint32_t)(len < 255 ? len : 255);
+            cnt = leaves ? P[c].cross_cnt : cnt;
+            // zc >= 128 (two varint bytes) only happens when the run leaves the lane
+            const bool wide = zc >= 128u;
+            const uint32_t o = active ? off : trash_off[c];
+            dst[c][o] = (uint8_t)(wide ? ((zc & 0x7Fu) | 0x80u) : zc);
+            dst[c][o + 1] = (uint8_t)(wide ? (zc >> 7) : cnt);
+            dst[c][(wide && active) ? off + 2 : trash_off[c]] = (uint8_t)cnt;
+        }
+    }
+    // values: every position stores two bytes, zeros go to the trash bytes
 #ifndef FLO_EMIT_NOVAL
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const uint32_t K = ((1u << i) - 1u) | (((2u << i) - 1u) << 16);
-        const uint32_t off = P.off0 + 2u * (uint32_t)__builtin_popcount(P.M & K);
-        const uint32_t o = ((m >> i) & 1u) ? off : trash_off;
-        const uint32_t v = (uint32_t)q[i];
-        dst[o] = (uint8_t)v;
-        dst[o + 1] = (uint8_t)(v >> 8);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const uint32_t K = ((1u << i) - 1u) | (((2u << i) - 1u) << 16);
+            const uint32_t off = P[c].off0 + 2u * (uint32_t)__builtin_popcount(P[c].M & K);
+            const uint32_t o = ((m[c] >> i) & 1u) ? off : trash_off[c];
+            const uint32_t v = (uint32_t)q[c][i];
+            dst[c][o] = (uint8_t)v;
+            dst[c][o + 1] = (uint8_t)(v >> 8);
+        }
     }
 #endif
+}
+
+// single channel
+__device__ __forceinline__ void sparse_emit(const int lane, const int (&q)[16], const SparsePlan &P, uint8_t *dst,
+                                            uint32_t trash_off) {
+    const int (&q1)[1][16] = reinterpret_cast<const int (&)[1][16]>(q);
+    const SparsePlan (&P1)[1] = reinterpret_cast<const SparsePlan (&)[1]>(P);
+    uint8_t *const d1[1] = {dst};
+    const uint32_t t1[1] = {trash_off};
+    sparse_emit_n<1>(lane, q1, P1, d1, t1);
 }
 
 }  // namespace flo

@@ -59,7 +59,7 @@ struct FrameState {
 #else
 #define ASTAMP(i) do {} while (0)
 #endif
-template <int CH, bool BANDS_ONLY, bool EXACT>
+template <int CH, bool BANDS_ONLY, bool EXACT, bool PLAN = true>
 __device__ __forceinline__ void analyse_frame(const int lane, float (&c)[CH][16], WaveLds<CH> &lds, const LaneConst &L,
                                               const LossyArgs &A, const LossyDevTables &T, int ch0, FrameState<CH> &st,
                                               unsigned long long gframe, int (&q)[CH][16], uint32_t (&sfw)[CH],
@@ -111,6 +111,7 @@ __device__ __forceinline__ void analyse_frame(const int lane, float (&c)[CH][16]
 #pragma unroll
         for (int ch = 0; ch < CH; ch++) A.dbg_sfw[(gframe * A.nch + ch0 + ch) * 25 + lane] = (unsigned short)sfw[ch];
     }
+    if (!PLAN) return;
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) sparse_plan(lane, q[ch], P[ch]);
 }
@@ -150,9 +151,17 @@ __device__ __forceinline__ uint32_t emit_frame(const int lane, uint8_t *f, int n
             uint8_t *p = f + chpos[c];
             p[0] = (uint8_t)l; p[1] = (uint8_t)(l >> 8); p[2] = (uint8_t)(l >> 16); p[3] = (uint8_t)(l >> 24);
         }
-        // trash bytes: past the end of the whole frame, two per lane (the staging buffer has 128 + bytes of slack)
-        sparse_emit(lane, q[ch], P[ch], f + chpos[c] + 4, (flen - (chpos[c] + 4)) + 2u * (uint32_t)lane);
     }
+    // trash bytes: past the end of the whole frame, two per lane and channel (the staging buffer has the slack)
+    uint8_t *dsts[CH];
+    uint32_t trash[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+        const int c = ch0 + ch;
+        dsts[ch] = f + chpos[c] + 4;
+        trash[ch] = (flen - (chpos[c] + 4)) + 2u * (uint32_t)lane + 128u * (uint32_t)ch;
+    }
+    sparse_emit_n<CH>(lane, q, P, dsts, trash);
     return flen;
 }
 
@@ -384,12 +393,183 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------- three waves per clip
+// Stereo clips as a two-stage pipeline: the two channel waves do transform, masking and quantiser of frame t + 1 while
+// a third wave (the packer) plans, serialises and flushes frame t of both channels. The channel waves hand the
+// quantised integers over through 2 KiB of LDS per channel (16 x i16 per lane); nothing else crosses waves, so the
+// sparse offsets, the frame header and the flush need no rendezvous at all. Bytes are identical to the two-wave form.
+struct Clip3Lds {
+    WaveLds<1> wl[2];
+    __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 256];
+    __attribute__((aligned(16))) uint32_t qh[2][512];   // [channel][half * 64 + lane] uint4: eight i16 pairs... two uint4 per lane
+    uint16_t sfwh[2][32];
+    uint32_t ready[2];      // frames published by channel wave w
+    uint32_t consumed;      // frames the packer has taken over
+    uint32_t pad;
+};
+static_assert(sizeof(Clip3Lds) % 16 == 0, "clip LDS block keeps 16-byte alignment");
+
+// wait until the LDS counter at `p` reaches `want` (written by another wave of this workgroup)
+__device__ __forceinline__ void wait_counter(const uint32_t *p, uint32_t want) {
+    const uint32_t a = (uint32_t)(uintptr_t)p;
+    uint32_t seen;
+    do {
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(a) : "memory");
+        if (seen >= want) break;
+        __builtin_amdgcn_s_sleep(1);
+    } while (true);
+}
+// publish: every LDS access this wave issued before is performed first (a wave's LDS instructions execute in order)
+__device__ __forceinline__ void set_counter(uint32_t *p, uint32_t v) {
+    const uint32_t a = (uint32_t)(uintptr_t)p;
+    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clips_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    {
+        float4 *dstp = reinterpret_cast<float4 *>(lds_raw);
+        for (int i = tid; i < kPackRows * 64; i += (int)blockDim.x) dstp[i] = A.T.pack[i];
+        for (int i = tid; i < clips_per_wg; i += (int)blockDim.x) {
+            Clip3Lds &c0 = *reinterpret_cast<Clip3Lds *>(lds_raw + kPackBytes + (size_t)i * sizeof(Clip3Lds));
+            c0.ready[0] = 0;
+            c0.ready[1] = 0;
+            c0.consumed = 0;
+        }
+    }
+    __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cl = wv / 3;                  // clip slot inside the workgroup
+    const int w = wv % 3;                   // 0, 1: channel waves; 2: packer
+    const unsigned clip = blockIdx.x * (unsigned)clips_per_wg + (unsigned)cl;
+    if (clip >= (unsigned)A.n_clips) return;
+    Clip3Lds &cs = *reinterpret_cast<Clip3Lds *>(lds_raw + kPackBytes + (size_t)cl * sizeof(Clip3Lds));
+    const unsigned hops = A.clip_hops[clip];
+    const unsigned long long frame0 = A.clip_frame0[clip];
+
+    if (w == 2) {
+        // ------------------------------------------------------------------ packer
+        uint8_t *stage = cs.stage;
+        uint8_t *gout = A.out + A.out_off[clip];
+        unsigned long long written = 0;
+        uint32_t pend = 0, tailb = 0;
+        for (unsigned h = 0; h < hops; h++) {
+            const int ln = lane_id_opaque();
+            wait_counter(&cs.ready[0], h + 1);
+            wait_counter(&cs.ready[1], h + 1);
+            int q[2][16];
+            uint32_t sfw[2];
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(cs.qh[ch]);
+                const uint4 x0 = src[ln], x1 = src[64 + ln];
+                const uint32_t xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    q[ch][2 * k] = (int)(short)(xs[k] & 0xFFFFu);
+                    q[ch][2 * k + 1] = (int)xs[k] >> 16;
+                }
+                sfw[ch] = cs.sfwh[ch][ln & 31];
+            }
+            set_counter(&cs.consumed, h + 1);
+            SparsePlan P[2];
+            sparse_plan(ln, q[0], P[0]);
+            sparse_plan(ln, q[1], P[1]);
+            uint32_t tot[2] = {P[0].total, P[1].total};
+            // the < 16 bytes the previous frame left unflushed go back to the front of the staging buffer
+            if (ln < (int)pend) stage[ln] = (uint8_t)tailb;
+            const uint32_t flen = emit_frame<2>(ln, stage + pend, 2, 0, tot, sfw, P, q);
+            wave_sync();
+            if (ln == 0) A.frame_size[frame0 + h] = flen;
+            const uint32_t have = pend + flen;
+            const uint32_t n16 = have >> 4;
+            const uint4 *src = reinterpret_cast<const uint4 *>(stage);
+            uint4 *dst = reinterpret_cast<uint4 *>(gout + written);
+            for (uint32_t i = ln; i < n16; i += 64) dst[i] = src[i];
+            pend = have & 15u;
+            tailb = (ln < (int)pend) ? stage[(n16 << 4) + ln] : 0u;
+            written += (unsigned long long)n16 << 4;
+            wave_sync();
+        }
+        if (lane < (int)pend) gout[written + lane] = (uint8_t)tailb;
+        if (lane == 0) A.clip_bytes[clip] = written + pend;
+        return;
+    }
+
+    // ---------------------------------------------------------------------- channel waves
+    WaveLds<1> &lds = cs.wl[w];
+    if (lane == 0) lds.slots[0][kZeroSlot] = make_float2(0.f, 0.f);
+    LossyDevTables T = A.T;
+    T.pack = reinterpret_cast<const float4 *>(lds_raw);
+    const float *pcm = A.pcm + A.clip_off[clip];
+    const long long n_sf = (long long)A.clip_nsf[clip];
+
+    FrameState<1> st;
+    st.prev[0] = 0.f;
+    float ae[1][8], ao[1][8], be[1][8], bo[1][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) ae[0][r] = ao[0][r] = 0.f;  // pre-roll: 1024 zeros (encoder.rs:177)
+    if (!A.in_coeffs) {
+        if (n_sf >= 1024) load_half_fast<1>(lane, pcm, 2, w, 0, be, bo);
+        else load_half<1>(lane, pcm, n_sf, 2, w, 0, be, bo);
+    }
+    auto frame_body = [&](const unsigned h, float (&pe)[1][8], float (&po)[1][8], float (&ce)[1][8],
+                          float (&co)[1][8]) __attribute__((always_inline)) {
+        const int ln = lane_id_opaque();
+        {
+            unsigned zero = 0;  // keep the (rarely used) global table out of loop-invariant registers
+            asm volatile("" : "+s"(zero));
+            T.ath_db += zero;
+        }
+        float c[1][16];
+        if (A.in_coeffs) {
+            load_coeffs<1>(ln, c, A, frame0 + h, w);
+        } else {
+            float zr[1][8], zi[1][8];
+            fold<1>(ln, pe, po, ce, co, zr, zi, T);
+            if (h + 1 < hops) {
+                const long long s0 = (long long)(h + 1) * 1024;
+                if (s0 + 1024 <= n_sf) load_half_fast<1>(ln, pcm, 2, w, s0, pe, po);
+                else load_half<1>(ln, pcm, n_sf, 2, w, s0, pe, po);
+            }
+            fft512<1>(ln, zr, zi, lds.u.xch, T);
+            post_rotate_transpose<1>(ln, zr, zi, lds.u.coef, c, T);
+            store_coeffs_dbg<1>(ln, c, A, frame0 + h, w);
+        }
+        int q[1][16];
+        uint32_t sfw[1];
+        SparsePlan P[1];
+        {
+            LaneConst L;
+            load_lane_const(ln, L, T);
+            analyse_frame<1, false, EXACT, false>(ln, c, lds, L, A, T, w, st, frame0 + h, q, sfw, P);
+        }
+        // hand over: sixteen i16 per lane as two uint4, the 25 scale words
+        uint32_t xs[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) xs[k] = __builtin_amdgcn_perm((uint32_t)q[0][2 * k + 1], (uint32_t)q[0][2 * k], 0x05040100u);
+        wait_counter(&cs.consumed, h);   // the packer has taken frame h - 1 out of the hand-over buffer
+        uint4 *dq = reinterpret_cast<uint4 *>(cs.qh[w]);
+        dq[ln] = make_uint4(xs[0], xs[1], xs[2], xs[3]);
+        dq[64 + ln] = make_uint4(xs[4], xs[5], xs[6], xs[7]);
+        if (ln < 25) cs.sfwh[w][ln] = (uint16_t)sfw[0];
+        set_counter(&cs.ready[w], h + 1);
+    };
+    for (unsigned h = 0; h < hops; h += 2) {
+        frame_body(h, ae, ao, be, bo);
+        if (h + 1 < hops) frame_body(h + 1, be, bo, ae, ao);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- frame-parallel
 // PASS 1: a_t only. PASS 2: full frame into slot gframe. One wave per frame, CH = all channels in lock-step.
 template <int CH, int PASS, bool EXACT>
 __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
     __shared__ WaveLds<CH> lds;
-    __shared__ __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 128];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 256];
     const int lane = lane_id();
     const unsigned long long gframe = blockIdx.x;
     if (gframe >= A.total_frames) return;
@@ -610,6 +790,35 @@ static int launch_chain_t(const LossyArgs &A, hipStream_t s) {
     hipLaunchKernelGGL((lossy_chain_kernel<NW, EXACT>), dim3(wgs), dim3(64 * NW * g), lds, s, A, g);
     FLO_LAUNCH_CHECK();
     return 0;
+}
+
+// clips per workgroup of the three-wave form: 15 waves (960 threads) and 160 KiB of LDS hold five
+int chain3_clips_per_wg(int n_clips) {
+    int g = (n_clips + 255) / 256;
+    const int gmax = (int)((160 * 1024 - kPackBytes) / sizeof(Clip3Lds));
+    if (g > gmax) g = gmax;
+    if (g > 5) g = 5;
+    return g < 1 ? 1 : g;
+}
+template <bool EXACT>
+static int launch_chain3_t(const LossyArgs &A, hipStream_t s) {
+    const int g = chain3_clips_per_wg(A.n_clips);
+    const size_t lds = kPackBytes + (size_t)g * sizeof(Clip3Lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lossy_chain3_kernel<EXACT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const unsigned wgs = (unsigned)((A.n_clips + g - 1) / g);
+    hipLaunchKernelGGL((lossy_chain3_kernel<EXACT>), dim3(wgs), dim3(192 * g), lds, s, A, g);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_lossy_chain3(const LossyArgs &A, hipStream_t s) {
+    if (A.nch != 2) return -1;
+    return A.exact ? launch_chain3_t<true>(A, s) : launch_chain3_t<false>(A, s);
 }
 
 int launch_lossy_chain(const LossyArgs &A, hipStream_t s) {

@@ -40,6 +40,7 @@ struct LossyArgs {
 };
 
 int launch_lossy_chain(const LossyArgs &A, hipStream_t s);
+int launch_lossy_chain3(const LossyArgs &A, hipStream_t s);   // stereo only: two channel waves + one packer wave per clip
 int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s);
 int launch_lossy_scan(const LossyArgs &A, hipStream_t s);
 int launch_lossy_compact(const LossyArgs &A, hipStream_t s);

@@ -78,8 +78,9 @@ int flo_batch_upload(flo_batch *b, size_t clip, const float *pcm);
 /* fill every clip with the integer-exact synthetic signal of flo_synth.h (device kernel), seeded by seed;
  * clip ids start at clip_id0 so that ranks of a sharded job generate disjoint parts of one corpus */
 int flo_batch_fill_synthetic(flo_batch *b, uint32_t seed, uint64_t clip_id0);
-/* launch the encode kernels on the ctx stream (asynchronous). which = 0: auto, 1: force the clip-chain
- * kernel, 2: force the frame-parallel kernels (lossy only; both produce identical bytes) */
+/* launch the encode kernels on the ctx stream (asynchronous). which = 0: auto, 1: clip-chain kernel with one wave
+ * per channel, 2: frame-parallel kernels, 3: clip-chain kernel with two channel waves + one packer wave per stereo
+ * clip (lossy only; all forms produce identical bytes) */
 int flo_batch_encode(flo_batch *b, int which);
 int flo_batch_sync(flo_batch *b);
 /* after sync: total compressed DATA bytes of the batch, and of one clip */
@@ -101,7 +102,8 @@ int flo_ctx_profile_enable(flo_ctx *ctx, int on);
 /* sum and count of bracketed launches of `kernel` since the last reset (call after a sync) */
 int flo_ctx_profile_query(flo_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 int flo_ctx_profile_reset(flo_ctx *ctx);
-/* test hook: force the lossy kernel form used by the one-shot entry points (0 auto, 1 chain, 2 frame-parallel) */
+/* test hook: force the lossy kernel form (0 auto, 1 chain with one wave per channel, 2 frame-parallel,
+ * 3 chain with two channel waves + one packer wave per stereo clip; 3 falls back to 1 for mono) */
 int flo_ctx_force_path(flo_ctx *ctx, int which);
 /* stream handle (hipStream_t) of the context, for callers that enqueue their own work around the encode */
 void *flo_ctx_stream(flo_ctx *ctx);

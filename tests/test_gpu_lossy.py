@@ -98,6 +98,23 @@ def test_chain_and_frame_parallel_forms_give_identical_files(ctx):
     a = ctx.encode_lossy(pcm, 44100, 2, 0.55)
     ctx.force_path(2)
     b = ctx.encode_lossy(pcm, 44100, 2, 0.55)
+    ctx.force_path(3)
+    c = ctx.encode_lossy(pcm, 44100, 2, 0.55)
+    ctx.force_path(0)
+    assert a == b
+    assert a == c
+
+
+@pytest.mark.parametrize("q", [0.0, 0.55, 1.0])
+def test_three_wave_pipeline_matches_chain_on_a_ragged_batch(ctx, q):
+    # clips of different lengths (and one empty) in one launch: the packer wave and the two channel waves of every
+    # clip run their own frame counts; bytes must equal the two-wave chain form
+    lens = [0, 1, 1023, 1024, 5000, 44100, 70001, 3 * 1024]
+    clips = [signals.music_like(44100, n, 2, seed=40 + i) for i, n in enumerate(lens)]
+    ctx.force_path(1)
+    a = ctx.encode_batch(1, clips, 44100, 2, q)
+    ctx.force_path(3)
+    b = ctx.encode_batch(1, clips, 44100, 2, q)
     ctx.force_path(0)
     assert a == b
 
@@ -147,7 +164,7 @@ def test_near_goldens_reference_made_files(ctx, name, q, src):
 @pytest.mark.parametrize("ch", [1, 2])
 def test_edge_lengths(ctx, n, ch):
     pcm = signals.fast_noise(n * ch, 7, 0.4)
-    for path in (1, 2):
+    for path in (1, 2, 3):
         ctx.force_path(path)
         g = ctx.encode_lossy(pcm, 44100, ch, 0.55)
         o = O.encode_lossy(pcm, 44100, ch, 0.55)
