@@ -25,6 +25,25 @@ ALG_BYTES_PER_SAMPLE = 4.0 + 2.0 + 50.0 / 1024.0   # f32 in + i16 out + 25 u16 s
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def hbm_traffic(kname, args):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of profiles/collect.sh (rocprofv3 cannot run
+    inside this process; the summary is of this same command and workload). None when there is no summary for the
+    kernel form and workload that just ran."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_profile_summary.json")
+    if args.clips_per_gpu != 1250 or args.clip_seconds != 10.0 or not os.path.exists(path):
+        return None, None
+    try:
+        with open(path) as fh:
+            ks = json.load(fh)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    for name, e in ks.items():
+        if ("::" + kname + "_kernel") in name and "hbm_read_bytes_per_launch" in e and "hbm_write_bytes_per_launch" in e:
+            return (int(e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]),
+                    "profiles/r01_profile_summary.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE, separate passes")
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,10 +152,12 @@ def main():
     }
     if k_n:
         per_launch_s = k_ms / k_n / 1e3
+        traffic, traffic_src = hbm_traffic(kname, args)
         achieved = ALG_BYTES_PER_SAMPLE * samples_per_step_rank / per_launch_s / 1e9
         out["roofline"] = {
             "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
+            "traffic_source": traffic_src,
             "kernel_ms": round(k_ms / k_n, 4), "algorithmic_bytes_per_sample": round(ALG_BYTES_PER_SAMPLE, 4),
         }
 

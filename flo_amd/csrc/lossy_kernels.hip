@@ -203,10 +203,10 @@ __device__ __forceinline__ void load_coeffs(const int lane, float (&c)[CH][16], 
 
 // ---------------------------------------------------------------------------------------------- chain kernel
 // One wavefront per (clip, channel); a workgroup hosts G clips (NW = channels = 1 or 2 waves each) that share ONE
-// copy of the constant pack in LDS (27 KiB: window, twiddles, ATH thresholds, band bookkeeping), so the only
+// copy of the constant pack in LDS (46 KiB: window, twiddles, ATH thresholds, band bookkeeping), so the only
 // global traffic of the frame loop is the PCM stream in and the bitstream out. Each wave walks its channel's
 // frames in order: the raw samples of the overlapping half-frame and the 25-float masking state stay in registers,
-// so every PCM sample is read from HBM once. The two waves of a stereo clip meet three times per frame (LDS flag
+// so every PCM sample is read from HBM once. The two waves of a stereo clip meet twice per frame (LDS flag
 // hand-shakes, no workgroup barrier: other clips of the workgroup never wait) to assemble and flush the frame.
 constexpr int kPackBytes = kPackRows * 64 * 16;
 struct ClipLds {

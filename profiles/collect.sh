@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collects the profile evidence bench.py's roofline numbers are checked against. Run on the GPU box from the repo
+# root:  profiles/collect.sh r01   -> gpurun_out/prof_r01/{stats,fetch,write,sq}/ + gpurun_out/prof_r01/summary.json
+# Passes are separate on purpose: --kernel-trace --stats alone for durations; FETCH_SIZE and WRITE_SIZE do not fit one
+# TCC pass; the SQ counters take another. No --pmc pass is combined with any API/runtime trace.
+set -e
+tag=${1:-r01}
+out=gpurun_out/prof_$tag
+mkdir -p $out
+export TMPDIR=/tmp
+BENCH="bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $out/stats -o run --output-format csv -- python $BENCH > $out/stats.log 2>&1
+tail -n 1 $out/stats.log > /dev/null
+SHORT="bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-single-clip"
+rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o run --output-format csv -- python $SHORT > $out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $out/write -o run --output-format csv -- python $SHORT > $out/write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE \
+    -d $out/sq -o run --output-format csv -- python $SHORT > $out/sq.log 2>&1
+python profiles/summarize.py $out > $out/summary.json
+cat $out/summary.json

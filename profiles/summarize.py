@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 CSVs written by profiles/collect.sh into one JSON document.
+
+Per kernel: launches and average duration from the --kernel-trace --stats pass; HBM bytes per launch from the
+FETCH_SIZE / WRITE_SIZE passes (rocprofv3 reports KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for
+gfx950, WRITE_SIZE is taken as is); SQ counters per launch from the SQ pass.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.split("(")[0]
+    return name.replace("void ", "").strip()
+
+
+def counters(d):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        per_dispatch = defaultdict(float)
+        names = {}
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                key = (r["Dispatch_Id"], r["Counter_Name"])
+                per_dispatch[key] += float(r["Counter_Value"])   # rows are per XCD / instance: sum them
+                names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+        for (disp, cn), v in per_dispatch.items():
+            acc[names[disp]][cn].append(v)
+    return {k: {cn: sum(v) / len(v) for cn, v in cs.items()} for k, cs in acc.items()}
+
+
+def main():
+    d = sys.argv[1]
+    out = {"source": d, "kernels": {}}
+    for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                out["kernels"][short(r["Name"])] = {"launches": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                                                    "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
+                                                    "percent": float(r["Percentage"])}
+    fetch, write, sq = counters(os.path.join(d, "fetch")), counters(os.path.join(d, "write")), counters(os.path.join(d, "sq"))
+    for k in set(fetch) | set(write) | set(sq):
+        e = out["kernels"].setdefault(k, {})
+        if k in fetch and "FETCH_SIZE" in fetch[k]:
+            e["hbm_read_bytes_per_launch"] = fetch[k]["FETCH_SIZE"] * 1024 * 2   # KiB, gfx950 x2 correction
+            e["FETCH_SIZE_raw_KiB"] = fetch[k]["FETCH_SIZE"]
+        if k in write and "WRITE_SIZE" in write[k]:
+            e["hbm_write_bytes_per_launch"] = write[k]["WRITE_SIZE"] * 1024
+        if k in sq:
+            e["sq_per_launch"] = sq[k]
+    json.dump(out, sys.stdout, indent=1, sort_keys=True)
+    print()
+
+
+if __name__ == "__main__":
+    main()
