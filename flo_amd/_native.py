@@ -17,7 +17,7 @@ MODE_LOSSLESS, MODE_LOSSY = 0, 1
 
 EXPORTS = [
     "flo_ctx_create", "flo_ctx_destroy", "flo_last_error", "flo_last_create_error", "flo_free", "flo_ctx_device_info",
-    "flo_encode_lossy", "flo_encode_lossless", "flo_encode_batch",
+    "flo_encode_lossy", "flo_encode_lossless", "flo_encode_batch", "flo_decode", "flo_decode_lossless_i32",
     "flo_batch_create", "flo_batch_destroy", "flo_batch_clip_device_ptr", "flo_batch_upload",
     "flo_batch_fill_synthetic", "flo_batch_encode", "flo_batch_sync", "flo_batch_data_bytes", "flo_batch_fetch",
     "flo_batch_device_streams", "flo_batch_pack_streams",
@@ -85,5 +85,7 @@ def lib():
     L.flo_lossy_analyze.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_float, vp, vp, vp, C.POINTER(sz)]
     L.flo_lossy_quantize.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_float, vp, vp]
     L.flo_sparse_pack.argtypes = [vp, vp, sz, vp, sz, vp]
+    L.flo_decode.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
+    L.flo_decode_lossless_i32.argtypes = L.flo_decode.argtypes
     _LIB = L
     return L

@@ -135,6 +135,25 @@ class Context:
             self._L.flo_free(outs[i])
         return res
 
+    def decode(self, flo: bytes, with_info=False):
+        """libflo::decode (lib.rs:296-315): interleaved f32 PCM of a .flo file, decoded on the device."""
+        return self._decode(self._L.flo_decode, np.float32, flo, with_info)
+
+    def decode_lossless_i32(self, flo: bytes, with_info=False):
+        """the integers a lossless file decodes to, before the 1/32767 scaling (bit-exact parity checks)"""
+        return self._decode(self._L.flo_decode_lossless_i32, np.int32, flo, with_info)
+
+    def _decode(self, fn, dtype, flo, with_info):
+        flo = bytes(flo)
+        out, n = C.c_void_p(), C.c_size_t()
+        sr, ch = C.c_uint32(), C.c_uint8()
+        self._chk(fn(self._h, flo, len(flo), C.byref(out), C.byref(n), C.byref(sr), C.byref(ch)))
+        try:
+            a = np.frombuffer(C.string_at(out.value, n.value * 4), dtype=dtype).copy() if n.value else np.zeros(0, dtype)
+        finally:
+            self._L.flo_free(out)
+        return (a, sr.value, ch.value) if with_info else a
+
     # -- stage-level entry points (parity tests) -----------------------------------------------------------
     def mdct_forward(self, frames):
         f = _f32(frames)
@@ -279,6 +298,16 @@ class Encoder:
         return ctx.encode_lossless(samples, self.sample_rate, self.channels, self.bit_depth, self.compression_level, metadata)
 
 
+class Decoder:
+    """lossless::Decoder (lossless/decoder.rs:6-18); like libflo::decode it also accepts transform files."""
+
+    def __init__(self, ctx: Context = None):
+        self._ctx = ctx or default_context()
+
+    def decode(self, data: bytes):
+        return self._ctx.decode(data)
+
+
 class TransformEncoder:
     """lossy::TransformEncoder — lossy/encoder.rs:6-53,167-239. One fresh encoder per clip is the contract."""
 
@@ -296,6 +325,11 @@ class TransformEncoder:
 
 
 LossyEncoder = TransformEncoder
+
+
+def decode(data: bytes):
+    """libflo::decode (lib.rs:296-315)"""
+    return default_context().decode(data)
 
 
 def encode(samples, sample_rate, channels, bit_depth, metadata=None) -> bytes:

@@ -1,0 +1,302 @@
+// decode_kernels.hip — device decode of .flo payloads for gfx950.
+//
+// Reference behaviour replaced (files under /root/reference/libflo/src):
+//   transform frames : lossy/decoder.rs:29-52 (dequantise), :61-131 (deserialize_frame), :134-188 (sparse + varint),
+//                      lossy/mdct.rs:231-290 (inverse MDCT), :437-468 (overlap-add), lib.rs:325-352 (first frame dropped)
+//   ALPC frames      : core/rice.rs:123-159 (decode_i32) + :217-259 (BitReader), lossless/decoder.rs:92-273
+//                      (decode_channel_int, reconstruct_lpc_int, reconstruct_fixed), :21-72 (mid/side, interleave)
+// The inverse transform reuses the in-wave FFT-512 of the encoder (lossy_device.hpp). Rice decoding and the LPC
+// recurrence are serial per channel of a frame, so the lossless side runs one thread per channel wrapper: slow per
+// clip, parallel over a batch.
+#include "decode_kernels.hpp"
+
+namespace flo {
+
+// ------------------------------------------------------------------------------------------------ transform frames
+constexpr int kMaxRecords = 1056;   // a record takes >= 2 bytes and a sparse blob is at most ~2.1 KB
+
+__device__ __forceinline__ uint32_t rd_u16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t rd_u32(const uint8_t *p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+__global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
+    __shared__ short q[1024];
+    __shared__ float xch[1][kXchFloats];
+    __shared__ float recon[2048];
+    __shared__ uint32_t rec_pos[kMaxRecords];   // output index | count << 16 (count <= 255, index < 1024)
+    __shared__ uint32_t rec_src[kMaxRecords];   // byte position of the record's first value
+    __shared__ float sf[32];
+    __shared__ int s_nrec;
+    const int lane = (int)threadIdx.x;
+    const unsigned clip = blockIdx.y, h = blockIdx.x;
+    if (clip >= (unsigned)D.n_clips || h >= D.clip_frames[clip]) return;
+    const unsigned long long f = D.clip_frame0[clip] + h;
+    const uint8_t *data = D.bytes + D.blob_off[f];
+    const uint32_t len = D.blob_len[f];
+    const unsigned nframes = D.clip_frames[clip];
+    float *out = D.out + D.clip_out[clip];
+
+    // deserialize_frame: [block_size][channels][25 x u16 per channel][per channel: u32 len, sparse bytes]
+    if (len < 2 || data[0] != 0 /* only Long blocks are produced or accepted */ || data[1] > D.channels) {
+        if (lane == 0) atomicExch(D.error, 1);
+        return;
+    }
+    const uint32_t nch = data[1];
+    uint32_t pos = 2 + 50 * nch;
+    if (pos > len) {
+        if (lane == 0) atomicExch(D.error, 1);
+        return;
+    }
+    for (uint32_t c = 0; c < nch; c++) {
+        if (pos + 4 > len) {
+            if (lane == 0) atomicExch(D.error, 1);
+            return;
+        }
+        const uint32_t blen = rd_u32(data + pos);
+        pos += 4;
+        if (pos + blen > len || pos + blen < pos) {
+            if (lane == 0) atomicExch(D.error, 1);
+            return;
+        }
+        const uint8_t *sp = data + pos;
+        pos += blen;
+        // scale factors: 2^((word - 32768) / 256), 0 when the word is 0 (decoder.rs:91-99)
+        if (lane < 25) {
+            const uint32_t wv = rd_u16(data + 2 + 50 * c + 2 * lane);
+            sf[lane] = wv > 0 ? powf(2.0f, ((float)wv - 32768.0f) / 256.0f) : 0.0f;
+        }
+        for (int i = lane; i < 1024; i += 64) q[i] = 0;
+        // deserialize_sparse (decoder.rs:134-167): lane 0 walks the record headers, then every lane copies records
+        if (lane == 0) {
+            uint32_t p = 0, nrec = 0;
+            unsigned long long oi = 0;
+            while (p < blen && oi < 1024) {
+                uint32_t value = 0, shift = 0;
+                while (p < blen) {   // decode_varint (:170-188)
+                    const uint32_t b = sp[p++];
+                    value |= (b & 0x7Fu) << shift;
+                    if (!(b & 0x80u)) break;
+                    shift += 7;
+                    if (shift >= 32) break;
+                }
+                oi += value;
+                if (p >= blen) break;
+                const uint32_t nz = sp[p++];
+                const uint32_t avail = (blen - p) >> 1;
+                const uint32_t room = oi < 1024 ? (uint32_t)(1024 - oi) : 0u;
+                uint32_t cnt = nz < avail ? nz : avail;
+                cnt = cnt < room ? cnt : room;
+                if (cnt && nrec < kMaxRecords) {
+                    rec_pos[nrec] = (uint32_t)oi | (cnt << 16);
+                    rec_src[nrec] = p;
+                    nrec++;
+                }
+                p += 2 * cnt;
+                oi += cnt;
+            }
+            s_nrec = (int)nrec;
+        }
+        __syncthreads();
+        for (int r = lane; r < s_nrec; r += 64) {
+            const uint32_t o = rec_pos[r] & 0xFFFFu, cnt = rec_pos[r] >> 16;
+            const uint8_t *v = sp + rec_src[r];
+            for (uint32_t i = 0; i < cnt; i++) q[o + i] = (short)rd_u16(v + 2 * i);
+        }
+        __syncthreads();
+        // dequantise (decoder.rs:35-48) straight into the inverse transform's pre-rotation (mdct.rs:238-247)
+        float zr[1][8], zi[1][8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int i = lane + 64 * r;
+            const int ke = 2 * i, ko = 1023 - 2 * i;
+            const float se = sf[D.T.band[ke]], so = sf[D.T.band[ko]];
+            const float even = se > 0.0f ? __fdiv_rn((float)q[ke], se) : 0.0f;
+            const float odd = -(so > 0.0f ? __fdiv_rn((float)q[ko], so) : 0.0f);
+            const float4 t4 = D.T.pack[(8 + (r >> 1)) * 64 + lane];
+            const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
+            zr[0][r] = odd * w.y - even * w.x;
+            zi[0][r] = odd * w.x + even * w.y;
+        }
+        fft512<1>(lane, zr, zi, xch, D.T);
+        // post-rotation, scale 2 / 1024 and window (mdct.rs:252-287); every output position is written exactly once
+        const float scale = 2.0f / 1024.0f;
+        const float *win = D.window;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int idx = lane + 64 * r;
+            const float4 t4 = D.T.pack[(8 + (r >> 1)) * 64 + lane];
+            const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
+            const float val_re = w.x * zr[0][r] + w.y * zi[0][r];
+            const float val_im = w.y * zr[0][r] - w.x * zi[0][r];
+            if (idx < 256) {
+                const int fi = 2 * idx, ri = 511 - 2 * idx;
+                recon[ri] = -val_im * scale * win[ri];
+                recon[512 + fi] = val_im * scale * win[512 + fi];
+                recon[1024 + ri] = val_re * scale * win[1024 + ri];
+                recon[1536 + fi] = val_re * scale * win[1536 + fi];
+            } else {
+                const int i2 = idx - 256;
+                const int fi = 2 * i2, ri = 511 - 2 * i2;
+                recon[fi] = -val_re * scale * win[fi];
+                recon[512 + ri] = val_re * scale * win[512 + ri];
+                recon[1024 + fi] = val_im * scale * win[1024 + fi];
+                recon[1536 + ri] = val_im * scale * win[1536 + ri];
+            }
+        }
+        __syncthreads();
+        // overlap-add (mdct.rs:449-456): output block h - 1 = first half of frame h + second half of frame h - 1.
+        // Each output sample receives exactly two contributions onto a zero: the float sum does not depend on order.
+        // The first frame's block is dropped (lib.rs:338-341), the last frame's second half is never emitted.
+        for (int j = lane; j < 1024; j += 64) {
+            if (h >= 1) atomicAdd(out + ((unsigned long long)(h - 1) * 1024 + j) * D.channels + c, recon[j]);
+            if (h + 1 < nframes) atomicAdd(out + ((unsigned long long)h * 1024 + j) * D.channels + c, recon[1024 + j]);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ALPC frames
+struct BitRd {   // rice.rs:217-259
+    const uint8_t *p;
+    uint32_t len, byte_pos, bit_pos;
+    __device__ __forceinline__ bool exhausted() const { return byte_pos >= len; }
+    __device__ __forceinline__ uint32_t bit() {
+        if (byte_pos >= len) return 0;
+        const uint32_t b = (p[byte_pos] >> (7 - bit_pos)) & 1u;
+        if (++bit_pos == 8) {
+            bit_pos = 0;
+            byte_pos++;
+        }
+        return b;
+    }
+};
+
+__device__ __forceinline__ int rice_next(BitRd &r, uint32_t k) {   // one value of decode_i32 (rice.rs:127-155)
+    if (r.exhausted()) return 0;
+    uint32_t quotient = 0;
+    while (!r.exhausted() && r.bit() == 1u) {
+        quotient++;
+        if (quotient > 255) break;
+    }
+    uint32_t rem = 0;
+    for (uint32_t i = 0; i < k; i++) rem = (rem << 1) | r.bit();
+    const uint32_t u = (quotient << (k & 31u)) | rem;   // release-mode Rust masks the shift amount
+    return (int)(u >> 1) ^ -(int)(u & 1u);
+}
+
+__global__ __launch_bounds__(64) void ll_decode_kernel(LlDecArgs A) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= A.n_ch) return;
+    const LlChannelDev c = A.ch[t];
+    int *out = A.scratch + c.out_off;
+    const uint8_t *res = A.bytes + c.off;
+    const uint32_t n = c.samples;
+    const bool has_coeffs = c.n_coeffs > 0, has_res = c.len > 0;
+    if (!has_coeffs && has_res && c.shift_bits >= 128) {
+        // fixed predictor (decoder.rs:186-266): warm-up with lower orders, then binomial recurrences, wrapping adds
+        const int order = c.shift_bits - 128;
+        BitRd r{res, c.len, 0, 0};
+        int s1 = 0, s2 = 0, s3 = 0, s4 = 0;   // s[i-1] .. s[i-4]
+        for (uint32_t i = 0; i < n; i++) {
+            const int rv = rice_next(r, c.rice_k);
+            int eff = order > 4 ? 0 : order;   // unknown orders copy the residuals
+            if ((int)i < eff) eff = (int)i;
+            long long pred = 0;
+            if (eff == 1) pred = s1;
+            else if (eff == 2) pred = 2ll * s1 - s2;
+            else if (eff == 3) pred = 3ll * s1 - 3ll * s2 + s3;
+            else if (eff == 4) pred = 4ll * s1 - 6ll * s2 + 4ll * s3 - s4;
+            const int v = (int)((unsigned)rv + (unsigned)(int)pred);
+            out[i] = v;
+            s4 = s3; s3 = s2; s2 = s1; s1 = v;
+        }
+        return;
+    }
+    if (has_coeffs) {
+        // reconstruct_lpc_int (decoder.rs:152-184): the first `order` values are the residuals themselves
+        const int order = c.n_coeffs;
+        BitRd r{res, c.len, 0, 0};
+        int hist[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) hist[j] = 0;   // hist[j] = s[i - 1 - j]
+        const uint32_t sh = c.shift_bits & 63u;
+        for (uint32_t i = 0; i < n; i++) {
+            const int rv = rice_next(r, c.rice_k);
+            int v = rv;
+            if ((int)i >= order) {
+                long long pred = 0;
+#pragma unroll
+                for (int j = 0; j < 12; j++)
+                    if (j < order) pred += (long long)c.coeffs[j] * (long long)hist[j];
+                v = (int)((unsigned)(int)(pred >> sh) + (unsigned)rv);
+            }
+            out[i] = v;
+#pragma unroll
+            for (int j = 11; j > 0; j--) hist[j] = hist[j - 1];
+            hist[0] = v;
+        }
+        return;
+    }
+    if (has_res) {   // raw PCM: complete i16 pairs, zero padding
+        uint32_t k = 0;
+        for (uint32_t i = 0; i + 1 < c.len && k < n; i += 2) out[k++] = (int)(short)rd_u16(res + i);
+        while (k < n) out[k++] = 0;
+        return;
+    }
+    for (uint32_t i = 0; i < n; i++) out[i] = 0;   // silence
+}
+
+// mid/side (decoder.rs:76-90: truncating halves of wrapping sums), interleave, i32 -> f32 (audio_constants.rs:23-26)
+__global__ __launch_bounds__(256) void ll_finish_kernel(LlFinishArgs A) {
+    const unsigned f = blockIdx.y;
+    if (f >= A.n_frames) return;
+    const LlFrameDev fr = A.fr[f];
+    const float scale = 1.0f / 32767.0f;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < fr.samples; i += gridDim.x * blockDim.x) {
+        if (fr.mid_side && fr.n_channels == 2) {
+            const int m = A.scratch[fr.scratch_off[0] + i], s = A.scratch[fr.scratch_off[1] + i];
+            const int l = (int)((unsigned)m + (unsigned)s) / 2, r = (int)((unsigned)m - (unsigned)s) / 2;
+            const unsigned long long o = (fr.out_off + i) * 2;
+            if (A.out) { A.out[o] = (float)l * scale; A.out[o + 1] = (float)r * scale; }
+            if (A.out_i32) { A.out_i32[o] = l; A.out_i32[o + 1] = r; }
+        } else {
+            for (unsigned c = 0; c < fr.n_channels && c < (unsigned)A.channels; c++) {
+                const int v = A.scratch[A.ch[fr.first_channel + c].out_off + i];
+                const unsigned long long o = (fr.out_off + i) * A.channels + c;
+                if (A.out) A.out[o] = (float)v * scale;
+                if (A.out_i32) A.out_i32[o] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+#define FLO_LAUNCH_CHECK()                      \
+    do {                                        \
+        hipError_t e_ = hipGetLastError();      \
+        if (e_ != hipSuccess) return (int)e_;   \
+    } while (0)
+
+int launch_lossy_decode(const LossyDecArgs &A, unsigned max_frames, hipStream_t s) {
+    if (!max_frames || !A.n_clips) return 0;
+    hipLaunchKernelGGL(lossy_decode_kernel, dim3(max_frames, (unsigned)A.n_clips), dim3(64), 0, s, A);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_ll_decode(const LlDecArgs &A, hipStream_t s) {
+    if (!A.n_ch) return 0;
+    hipLaunchKernelGGL(ll_decode_kernel, dim3((A.n_ch + 63) / 64), dim3(64), 0, s, A);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_ll_finish(const LlFinishArgs &A, unsigned max_samples, hipStream_t s) {
+    if (!A.n_frames || !max_samples) return 0;
+    unsigned bx = (max_samples + 255) / 256;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(ll_finish_kernel, dim3(bx, A.n_frames), dim3(256), 0, s, A);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace flo

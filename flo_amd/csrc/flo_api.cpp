@@ -12,6 +12,7 @@
 
 #include "../../include/flo_hip.h"
 #include "container.hpp"
+#include "decode_kernels.hpp"
 #include "lossless_kernels.hpp"
 #include "lossy_kernels.hpp"
 #include "tables.hpp"
@@ -23,6 +24,7 @@ struct TableSet {
     LossyTablesHost host;
     void *blob = nullptr;  // one device allocation holding every table
     LossyDevTables dev{};
+    const float *dev_window = nullptr;  // [2048], decode side
 };
 
 struct ProfRec {
@@ -198,7 +200,8 @@ static int get_tables(flo_ctx *c, uint32_t sr, float quality, TableSet **out) {
     size_t i_pack = add(h.pack.data(), h.pack.size() * 4), i_athdb = add(h.ath_db.data(), h.ath_db.size() * 4),
            i_band = add(h.band.data(), h.band.size()), i_bc = add(h.band_count.data(), h.band_count.size() * 4),
            i_s10 = add(h.s10d.data(), h.s10d.size() * 4), i_lb = add(h.lane_bnd.data(), h.lane_bnd.size() * 4),
-           i_ls = add(h.lane_slot0.data(), h.lane_slot0.size() * 4), i_bs = add(h.band_slot0.data(), h.band_slot0.size() * 4);
+           i_ls = add(h.lane_slot0.data(), h.lane_slot0.size() * 4), i_bs = add(h.band_slot0.data(), h.band_slot0.size() * 4),
+           i_win = add(h.window.data(), h.window.size() * 4);
     hipError_t e = hipMalloc(&t->blob, total);
     if (e != hipSuccess) {
         delete t;
@@ -221,6 +224,7 @@ static int get_tables(flo_ctx *c, uint32_t sr, float quality, TableSet **out) {
     t->dev.lane_bnd = (const uint32_t *)P(i_lb);
     t->dev.lane_slot0 = (const uint32_t *)P(i_ls);
     t->dev.band_slot0 = (const uint32_t *)P(i_bs);
+    t->dev_window = (const float *)P(i_win);
     t->dev.max_band_slots = h.max_band_slots;
     t->dev.smr_thr = h.smr_threshold;
     t->dev.q_transparent = h.q_transparent;
@@ -772,4 +776,195 @@ extern "C" int flo_sparse_pack(flo_ctx *c, const int16_t *q, size_t n_vec, uint8
         out_off[i + 1] = (uint32_t)pos;
     }
     return FLO_OK;
+}
+
+// ---- decode ---------------------------------------------------------------------------------------------------
+namespace {
+struct DevMem {   // frees on scope exit
+    void *p = nullptr;
+    ~DevMem() {
+        if (p) hipFree(p);
+    }
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+template <class T>
+int upload(flo_ctx *c, DevMem &m, const std::vector<T> &v) {
+    size_t bytes = v.size() * sizeof(T);
+    HIPCHK(c, hipMalloc(&m.p, bytes ? bytes : 16));
+    if (bytes) HIPCHK(c, hipMemcpyAsync(m.p, v.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    return FLO_OK;
+}
+}  // namespace
+
+// libflo::decode (lib.rs:296-315): parse on the host (a few bytes per frame), decode on the device.
+static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, int32_t **pcm_i32, size_t *n_interleaved,
+                       uint32_t *sample_rate, uint8_t *channels) {
+    if (!c || !flo || !n_interleaved || (!pcm && !pcm_i32)) return fail(c, FLO_ERR_ARG, "null argument");
+    if (pcm) *pcm = nullptr;
+    if (pcm_i32) *pcm_i32 = nullptr;
+    *n_interleaved = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    ParsedFile f;
+    const char *perr = "";
+    if (parse_file(flo, len, f, &perr) != 0) return fail(c, FLO_ERR_FORMAT, perr);
+    if (sample_rate) *sample_rate = f.sample_rate;
+    if (channels) *channels = f.channels;
+    const int nch = f.channels;
+    DevMem d_bytes;
+    HIPCHK(c, hipMalloc(&d_bytes.p, len ? len : 16));
+    HIPCHK(c, hipMemcpyAsync(d_bytes.p, flo, len, hipMemcpyHostToDevice, c->stream));
+
+    if (f.is_transform) {
+        if (pcm_i32 && !pcm) return fail(c, FLO_ERR_ARG, "integer output exists for lossless files only");
+        // decode_transform_file (lib.rs:325-352): frames without channels are skipped, the first decoded frame is dropped
+        std::vector<unsigned long long> blob_off;
+        std::vector<unsigned int> blob_len;
+        for (const FrameDesc &fr : f.frames) {
+            if (!fr.n_channels) continue;
+            const ChannelDesc &cd = f.channels_desc[fr.first_channel];
+            blob_off.push_back(cd.off);
+            blob_len.push_back(cd.len);
+        }
+        const size_t nf = blob_off.size();
+        const size_t n_out = nf > 1 ? (nf - 1) * 1024 * (size_t)nch : 0;
+        float *host = (float *)malloc(n_out ? n_out * sizeof(float) : 1);
+        if (!host) return fail(c, FLO_ERR_NOMEM, "out of host memory");
+        if (nf) {
+            if (nch == 0) {
+                free(host);
+                return fail(c, FLO_ERR_FORMAT, "Failed to deserialize transform frame");
+            }
+            TableSet *ts;
+            int rc = get_tables(c, f.sample_rate, 0.5f, &ts);
+            if (rc != FLO_OK) {
+                free(host);
+                return rc;
+            }
+            DevMem d_off, d_len, d_c0, d_cn, d_co, d_out, d_err;
+            std::vector<unsigned long long> c0{0}, co{0};
+            std::vector<unsigned int> cn{(unsigned int)nf};
+            std::vector<int> zero{0};
+            if ((rc = upload(c, d_off, blob_off)) || (rc = upload(c, d_len, blob_len)) || (rc = upload(c, d_c0, c0)) ||
+                (rc = upload(c, d_cn, cn)) || (rc = upload(c, d_co, co)) || (rc = upload(c, d_err, zero))) {
+                free(host);
+                return rc;
+            }
+            hipError_t e = hipMalloc(&d_out.p, n_out ? n_out * sizeof(float) : 16);
+            if (e == hipSuccess && n_out) e = hipMemsetAsync(d_out.p, 0, n_out * sizeof(float), c->stream);
+            if (e != hipSuccess) {
+                free(host);
+                return fail(c, FLO_ERR_NOMEM, std::string("decode output: ") + hipGetErrorString(e));
+            }
+            LossyDecArgs A{};
+            A.T = ts->dev;
+            A.window = ts->dev_window;
+            A.bytes = d_bytes.as<uint8_t>();
+            A.blob_off = d_off.as<unsigned long long>();
+            A.blob_len = d_len.as<unsigned int>();
+            A.clip_frame0 = d_c0.as<unsigned long long>();
+            A.clip_frames = d_cn.as<unsigned int>();
+            A.clip_out = d_co.as<unsigned long long>();
+            A.n_clips = 1;
+            A.channels = nch;
+            A.out = d_out.as<float>();
+            A.error = d_err.as<int>();
+            rc = timed_launch(c, "lossy_decode", [&] { return launch_lossy_decode(A, (unsigned)nf, c->stream); });
+            int herr = 0;
+            if (rc == FLO_OK) {
+                e = hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess && n_out) e = hipMemcpyAsync(host, d_out.p, n_out * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e != hipSuccess) rc = fail(c, FLO_ERR_DEVICE, std::string("lossy decode: ") + hipGetErrorString(e));
+            }
+            if (rc == FLO_OK && herr) rc = fail(c, FLO_ERR_FORMAT, "Failed to deserialize transform frame");
+            if (rc != FLO_OK) {
+                free(host);
+                return rc;
+            }
+        }
+        *pcm = host;
+        *n_interleaved = n_out;
+        return FLO_OK;
+    }
+
+    // lossless (lossless/decoder.rs:21-72)
+    std::vector<LlChannelDev> chs;
+    std::vector<LlFrameDev> frs;
+    unsigned long long scratch = 0, out_sf = 0;
+    unsigned max_samples = 0;
+    for (const FrameDesc &fr : f.frames) {
+        LlFrameDev fd{};
+        fd.out_off = out_sf;
+        fd.first_channel = (unsigned)chs.size();
+        fd.n_channels = fr.n_channels;
+        fd.samples = fr.samples;
+        fd.mid_side = (nch == 2 && (fr.flags & 1)) ? 1u : 0u;
+        for (unsigned k = 0; k < fr.n_channels; k++) {
+            const ChannelDesc &cd = f.channels_desc[fr.first_channel + k];
+            LlChannelDev d{};
+            d.off = cd.off;
+            d.out_off = scratch;
+            d.len = cd.len;
+            d.samples = fr.samples;
+            d.n_coeffs = cd.n_coeffs;
+            d.shift_bits = cd.shift_bits;
+            d.rice_k = cd.rice_k;
+            memcpy(d.coeffs, cd.coeffs, sizeof d.coeffs);
+            if (k < 2) fd.scratch_off[k] = scratch;
+            scratch += fr.samples;
+            chs.push_back(d);
+        }
+        out_sf += fr.samples;
+        if (fr.samples > max_samples) max_samples = fr.samples;
+        frs.push_back(fd);
+    }
+    const size_t n_out = nch ? (size_t)out_sf * (size_t)nch : 0;
+    float *host = pcm ? (float *)malloc(n_out ? n_out * sizeof(float) : 1) : nullptr;
+    int32_t *host_i = pcm_i32 ? (int32_t *)malloc(n_out ? n_out * sizeof(int32_t) : 1) : nullptr;
+    auto bail = [&](int rc) {
+        free(host);
+        free(host_i);
+        return rc;
+    };
+    if ((pcm && !host) || (pcm_i32 && !host_i)) return bail(fail(c, FLO_ERR_NOMEM, "out of host memory"));
+    if (n_out) {
+        DevMem d_ch, d_fr, d_scr, d_out, d_outi;
+        int rc;
+        if ((rc = upload(c, d_ch, chs)) || (rc = upload(c, d_fr, frs))) return bail(rc);
+        hipError_t e = hipMalloc(&d_scr.p, scratch ? scratch * sizeof(int) : 16);
+        if (e == hipSuccess && host) {
+            e = hipMalloc(&d_out.p, n_out * sizeof(float));
+            if (e == hipSuccess) e = hipMemsetAsync(d_out.p, 0, n_out * sizeof(float), c->stream);
+        }
+        if (e == hipSuccess && host_i) {
+            e = hipMalloc(&d_outi.p, n_out * sizeof(int));
+            if (e == hipSuccess) e = hipMemsetAsync(d_outi.p, 0, n_out * sizeof(int), c->stream);
+        }
+        if (e != hipSuccess) return bail(fail(c, FLO_ERR_NOMEM, std::string("decode buffers: ") + hipGetErrorString(e)));
+        LlDecArgs A{d_bytes.as<uint8_t>(), d_ch.as<LlChannelDev>(), (unsigned)chs.size(), d_scr.as<int>()};
+        rc = timed_launch(c, "ll_decode", [&] { return launch_ll_decode(A, c->stream); });
+        if (rc != FLO_OK) return bail(rc);
+        LlFinishArgs F{d_fr.as<LlFrameDev>(), d_ch.as<LlChannelDev>(), (unsigned)frs.size(), nch, d_scr.as<int>(),
+                       d_out.as<float>(), d_outi.as<int>()};
+        rc = timed_launch(c, "ll_finish", [&] { return launch_ll_finish(F, max_samples, c->stream); });
+        if (rc != FLO_OK) return bail(rc);
+        if (host) e = hipMemcpyAsync(host, d_out.p, n_out * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && host_i) e = hipMemcpyAsync(host_i, d_outi.p, n_out * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return bail(fail(c, FLO_ERR_DEVICE, std::string("lossless decode: ") + hipGetErrorString(e)));
+    }
+    if (pcm) *pcm = host;
+    if (pcm_i32) *pcm_i32 = host_i;
+    *n_interleaved = n_out;
+    return FLO_OK;
+}
+
+extern "C" int flo_decode(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, size_t *n_interleaved,
+                          uint32_t *sample_rate, uint8_t *channels) {
+    return decode_impl(c, flo, len, pcm, nullptr, n_interleaved, sample_rate, channels);
+}
+extern "C" int flo_decode_lossless_i32(flo_ctx *c, const uint8_t *flo, size_t len, int32_t **pcm, size_t *n_interleaved,
+                                       uint32_t *sample_rate, uint8_t *channels) {
+    return decode_impl(c, flo, len, nullptr, pcm, n_interleaved, sample_rate, channels);
 }

@@ -9,7 +9,9 @@
  *   flo_encode_lossless   <- lossless::Encoder::new(sr,ch,bits).with_compression(level).encode(samples, meta)
  *                            libflo/src/lossless/encoder.rs:17-45
  *   flo_encode_batch      <- the same two calls, once per clip (callers loop in reflo/src/lib.rs:286-306)
- *   flo_free              <- drop of the returned Vec<u8>
+ *   flo_decode            <- libflo::decode(data) / lossless::Decoder::new().decode(data)
+ *                            libflo/src/lib.rs:296-352, lossless/decoder.rs:14-72, lossy/decoder.rs:29-188
+ *   flo_free              <- drop of the returned Vec<u8> / Vec<f32>
  *   error codes + flo_last_error <- FloResult<T> = Result<T, String>   (core/types.rs:281)
  *
  * Conventions mirror the reference: inputs are interleaved f32 PCM in [-1,1], length
@@ -19,7 +21,7 @@
  * thread / GPU; contexts are independent. A "fresh encoder per clip" is the contract for lossy encodes
  * (the reference never resets the psychoacoustic state between calls; all its callers build a new encoder).
  *
- * There is NO CPU fallback: every encode entry point runs the HIP kernels on the context's device and
+ * There is NO CPU fallback: every encode and decode entry point runs the HIP kernels on the context's device and
  * fails with a non-zero code if no gfx950 device is usable.
  */
 #ifndef FLO_HIP_H
@@ -37,6 +39,7 @@ extern "C" {
 #define FLO_ERR_DEVICE 2   /* HIP runtime / device error (text in flo_last_error) */
 #define FLO_ERR_NOMEM 3
 #define FLO_ERR_STATE 4    /* call sequence error on a batch object */
+#define FLO_ERR_FORMAT 5   /* not a decodable .flo file; flo_last_error holds the reference reader's message */
 
 #define FLO_MODE_LOSSLESS 0
 #define FLO_MODE_LOSSY 1
@@ -62,6 +65,18 @@ int flo_encode_lossless(flo_ctx *ctx, const float *pcm, size_t n_interleaved, ui
 int flo_encode_batch(flo_ctx *ctx, int mode, size_t n_clips, const float *const *pcm, const size_t *n_interleaved,
                      uint32_t sample_rate, uint8_t channels, float quality_or_level, uint8_t **outs,
                      size_t *out_lens);
+
+/* ---- one .flo file in, interleaved f32 PCM out (host buffers) ---------------------------------------------
+ * Replaces libflo::decode (lib.rs:296-315): files with a transform frame go through the device inverse MDCT
+ * (first frame dropped as the reference does: (frames - 1) * 1024 sample-frames come back), all others through the
+ * device Rice / predictor kernels (bit-exact integers, then * 1/32767). The container is parsed on the host like
+ * Reader::read (reader.rs:16-256): its error strings come back through flo_last_error with FLO_ERR_FORMAT. Like the
+ * reference, the CRC is not verified by decode. *pcm is malloc'ed (flo_free); sample_rate / channels may be NULL. */
+int flo_decode(flo_ctx *ctx, const uint8_t *flo, size_t len, float **pcm, size_t *n_interleaved,
+               uint32_t *sample_rate, uint8_t *channels);
+/* the integers before the float conversion (lossless files only): what parity tests compare bit for bit */
+int flo_decode_lossless_i32(flo_ctx *ctx, const uint8_t *flo, size_t len, int32_t **pcm, size_t *n_interleaved,
+                            uint32_t *sample_rate, uint8_t *channels);
 
 /* ---- device-resident batch (the throughput path: PCM already in HBM, bitstreams left in HBM) -------- */
 typedef struct flo_batch flo_batch;

@@ -1,0 +1,142 @@
+"""Device decode (flo_decode) against the oracle decoder and the reference's own fixture files.
+
+Lossless files: the decoded integers are compared bit for bit, the floats bit for bit as well (one multiply by the
+f32 constant 1/32767). Transform files: the inverse MDCT runs a different FFT than the oracle's, so PCM is compared
+within 2e-6 absolute on full-scale audio (the encoder-side coefficient tolerance is 1e-5 relative RMS) and the file
+geometry exactly. All calls go through the C ABI. Needs an MI355X."""
+import numpy as np
+import pytest
+
+import flofile
+import signals
+from conftest import example_bytes
+from fixtures_util import LOSSLESS_EXAMPLES, LOSSY_EXAMPLES
+from gpu_util import ctx, snr_db  # noqa: F401
+from oracle import oracle as O
+
+import flo_amd
+
+pytestmark = pytest.mark.gpu
+
+LOSSY_TOL = 2e-6
+
+
+@pytest.mark.parametrize("name", LOSSLESS_EXAMPLES + ["audio_lossless"])
+def test_lossless_fixture_files_decode_bit_exactly(ctx, name):
+    b = example_bytes(name + ".flo")
+    oi, sr, ch = O.decode_lossless_i32(b)
+    gi, gsr, gch = ctx.decode_lossless_i32(b, with_info=True)
+    assert (gsr, gch) == (sr, ch)
+    assert np.array_equal(gi, oi)
+    of, _, _ = O.decode(b)
+    gf = ctx.decode(b)
+    assert gf.dtype == np.float32 and np.array_equal(gf.view(np.uint32), of.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,q,src", LOSSY_EXAMPLES + [("audio_lossy", 0.6, None)])
+def test_reference_made_transform_files_decode_like_the_oracle(ctx, name, q, src):
+    b = example_bytes(name + ".flo")
+    of, sr, ch = O.decode(b)
+    gf, gsr, gch = ctx.decode(b, with_info=True)
+    assert (gsr, gch) == (sr, ch) and gf.shape == of.shape
+    n_frames = len(flofile.parse(b).frames)
+    assert gf.size == (n_frames - 1) * 1024 * ch          # the first frame is dropped (lib.rs:338-341)
+    assert np.max(np.abs(gf - of), initial=0.0) <= LOSSY_TOL
+
+
+@pytest.mark.parametrize("sr,ch,level", [(44100, 2, 5), (44100, 1, 5), (96000, 2, 5), (8000, 1, 9), (44100, 2, 2), (48000, 2, 8)])
+def test_lossless_round_trip_through_the_device_both_ways(ctx, sr, ch, level):
+    # encode on the device, decode on the device: exactly the integers the reference's f32_to_i32 makes of the input
+    pcm = signals.music_like(sr, int(2.3 * sr), ch, seed=sr + level)
+    flo = ctx.encode_lossless(pcm, sr, ch, 16, level)
+    want = np.trunc(np.clip(pcm.astype(np.float32) * np.float32(32767.0), -32768.0, 32767.0)).astype(np.int32)
+    got = ctx.decode_lossless_i32(flo)
+    assert np.array_equal(got, want[: got.size]) and got.size == want.size
+    assert np.array_equal(ctx.decode(flo).view(np.uint32), O.decode(flo)[0].view(np.uint32))
+
+
+def test_lossless_special_frames(ctx):
+    sr = 44100
+    # silence frame, raw frame (noise at full scale: nothing beats raw), mid/side frame, a partial last frame
+    rng = np.random.default_rng(5)
+    sil = np.zeros(sr * 2, np.float32)
+    noise = rng.uniform(-1, 1, sr * 2).astype(np.float32)
+    t = np.arange(sr) / sr
+    l = (0.4 * np.sin(2 * np.pi * 330 * t)).astype(np.float32)
+    ms = np.stack([l, l * 0.98], axis=1).reshape(-1)
+    tail = signals.music_like(sr, 1234, 2, seed=9)
+    pcm = np.concatenate([sil, noise, ms, tail])
+    flo = ctx.encode_lossless(pcm, sr, 2, 16, 5)
+    f = flofile.parse(flo)
+    assert f.frames[0].frame_type == 0 and any(fr.flags & 1 for fr in f.frames)
+    oi, _, _ = O.decode_lossless_i32(flo)
+    assert np.array_equal(ctx.decode_lossless_i32(flo), oi)
+
+
+def test_level0_files_decode_like_the_reference_not_like_the_input(ctx):
+    # the Raw-labelled Rice quirk: the reference cannot decode its own level-0 output; neither may we
+    pcm = signals.music_like(44100, 30000, 2, seed=3)
+    flo = O.encode_lossless(pcm, 44100, 2, 16, 0)
+    oi, _, _ = O.decode_lossless_i32(flo)
+    assert np.array_equal(ctx.decode_lossless_i32(flo), oi)
+
+
+@pytest.mark.parametrize("q", [0.0, 0.35, 0.55, 1.0])
+@pytest.mark.parametrize("ch", [1, 2])
+def test_transform_round_trip_on_the_device(ctx, q, ch):
+    sr = 44100
+    pcm = signals.music_like(sr, 3 * sr + 777, ch, seed=17 + ch)
+    flo = ctx.encode_lossy(pcm, sr, ch, q)
+    g = ctx.decode(flo)
+    o, _, _ = O.decode(flo)
+    assert g.shape == o.shape and np.max(np.abs(g - o)) <= LOSSY_TOL
+    # the reference's own acceptance bar for the codec (lossy tests: SNR well above 10 dB on tonal material)
+    n = min(g.size, pcm.size)
+    assert snr_db(pcm[:n], g[:n]) > (10.0 if q < 0.9 else 40.0)
+
+
+def test_long_zero_runs_and_dense_frames_decode(ctx):
+    # q = 1.0 on noise gives 255-capped records and dense frames; near-silence gives 3-byte varints and empty frames
+    sr = 44100
+    a = signals.fast_noise(40000 * 2, 11, 0.9)
+    b = np.zeros(30000 * 2, np.float32)
+    b[12345] = 0.5
+    for pcm, q in ((a, 1.0), (b, 0.55), (np.concatenate([a, b]), 0.8)):
+        flo = ctx.encode_lossy(pcm, sr, 2, q)
+        g = ctx.decode(flo)
+        o, _, _ = O.decode(flo)
+        assert g.shape == o.shape and np.max(np.abs(g - o), initial=0.0) <= LOSSY_TOL * max(1.0, float(np.max(np.abs(o), initial=0.0)))
+
+
+def test_empty_and_tiny_files(ctx):
+    for n in (0, 1, 1024, 1025):
+        pcm = signals.fast_noise(n * 2, 4, 0.3)
+        for flo in (ctx.encode_lossy(pcm, 44100, 2, 0.55), ctx.encode_lossless(pcm, 44100, 2, 16, 5)):
+            g = ctx.decode(flo)
+            o, _, _ = O.decode(flo)
+            assert g.shape == o.shape
+            assert np.max(np.abs(g - o), initial=0.0) <= LOSSY_TOL
+
+
+def test_malformed_input_is_an_error_not_a_crash(ctx):
+    good = ctx.encode_lossy(signals.music_like(44100, 5000, 2, seed=1), 44100, 2, 0.55)
+    with pytest.raises(flo_amd.FloError, match="bad magic"):
+        ctx.decode(b"RIFF" + good[4:])
+    with pytest.raises(flo_amd.FloError, match="Unexpected end of file"):
+        ctx.decode(good[:40])
+    with pytest.raises(flo_amd.FloError):
+        ctx.decode(good[: len(good) // 2])
+    # a transform blob that claims more channels than the header has
+    f = flofile.parse(good)
+    bad = bytearray(good)
+    blob0 = 70 + f.toc_size + 10 + 1       # header, TOC, frame header + channel size, then [block_size][channels]
+    bad[blob0] = 7
+    with pytest.raises(flo_amd.FloError, match="deserialize"):
+        ctx.decode(bytes(bad))
+
+
+def test_module_level_decode_and_decoder_class(ctx):
+    pcm = signals.music_like(44100, 20000, 2, seed=8)
+    flo = ctx.encode_lossless(pcm, 44100, 2, 16, 5)
+    a = flo_amd.Decoder(ctx).decode(flo)
+    assert np.array_equal(a.view(np.uint32), O.decode(flo)[0].view(np.uint32))
