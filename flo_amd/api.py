@@ -12,6 +12,7 @@ Errors surface as FloError(message), the analogue of FloResult<T> = Result<T, St
 """
 import ctypes as C
 import enum
+import weakref
 
 import numpy as np
 
@@ -77,9 +78,12 @@ class Context:
         if rc != 0:
             raise FloError(self._L.flo_last_create_error().decode())
         self._h = h
+        self._batches = weakref.WeakSet()   # batches hold device memory of this context: they go first
 
     def close(self):
         if getattr(self, "_h", None):
+            for b in list(self._batches):
+                b.close()
             self._L.flo_ctx_destroy(self._h)
             self._h = None
 
@@ -218,6 +222,7 @@ class Batch:
         h = C.c_void_p()
         ctx._chk(self._L.flo_batch_create(ctx._h, mode, self.n_clips, lens, sample_rate, channels, quality_or_level, C.byref(h)))
         self._h = h
+        ctx._batches.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -263,6 +268,12 @@ class Batch:
         offs = (C.c_uint64 * (self.n_clips + 1))()
         self.ctx._chk(self._L.flo_batch_pack_streams(self._h, dst_ptr, dst_cap, offs))
         return list(offs)
+
+    def decode_to(self, dst_ptr: int, dst_cap_floats: int):
+        """Decode every clip of an encoded lossy batch into device memory; returns the per-clip float offsets."""
+        offs = (C.c_uint64 * max(self.n_clips, 1))()
+        self.ctx._chk(self._L.flo_batch_decode(self._h, dst_ptr, dst_cap_floats, offs))
+        return list(offs[: self.n_clips])
 
     def device_streams(self):
         base = C.c_void_p()

@@ -960,6 +960,64 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
     return FLO_OK;
 }
 
+// Decode every clip of an encoded lossy batch from its device bitstreams (no host round trip of the payload).
+extern "C" int flo_batch_decode(flo_batch *b, float *dst, size_t dst_cap, uint64_t *offsets) {
+    if (!b || !offsets || (!dst && dst_cap)) return FLO_ERR_ARG;
+    flo_ctx *c = b->ctx;
+    if (b->mode != FLO_MODE_LOSSY) return fail(c, FLO_ERR_ARG, "flo_batch_decode handles lossy batches");
+    if (!b->synced) return fail(c, FLO_ERR_STATE, "call flo_batch_encode + flo_batch_sync first");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<unsigned long long> blob_off(b->total_frames), c0(b->n_clips), co(b->n_clips);
+    std::vector<unsigned int> blob_len(b->total_frames), cn(b->n_clips);
+    uint64_t total = 0;
+    unsigned max_hops = 0;
+    for (size_t i = 0; i < b->n_clips; i++) {
+        uint64_t off = b->out_off[i];
+        for (uint32_t h = 0; h < b->hops[i]; h++) {
+            const uint32_t fs = b->h_frame_size[b->clip_frame0[i] + h];
+            if (fs < 10) return fail(c, FLO_ERR_STATE, "batch holds a frame shorter than its header");
+            blob_off[b->clip_frame0[i] + h] = off + 10;   // [type][u32 samples][flags][u32 size] (writer.rs:236-254)
+            blob_len[b->clip_frame0[i] + h] = fs - 10;
+            off += fs;
+        }
+        c0[i] = b->clip_frame0[i];
+        cn[i] = b->hops[i];
+        co[i] = total;
+        offsets[i] = total;
+        total += b->hops[i] > 1 ? (uint64_t)(b->hops[i] - 1) * 1024 * b->ch : 0;
+        if (b->hops[i] > max_hops) max_hops = b->hops[i];
+    }
+    if (total > dst_cap) return fail(c, FLO_ERR_ARG, "destination too small for the decoded batch");
+    if (!total) return FLO_OK;
+    DevMem d_off, d_len, d_c0, d_cn, d_co, d_err;
+    std::vector<int> zero{0};
+    int rc;
+    if ((rc = upload(c, d_off, blob_off)) || (rc = upload(c, d_len, blob_len)) || (rc = upload(c, d_c0, c0)) ||
+        (rc = upload(c, d_cn, cn)) || (rc = upload(c, d_co, co)) || (rc = upload(c, d_err, zero)))
+        return rc;
+    HIPCHK(c, hipMemsetAsync(dst, 0, total * sizeof(float), c->stream));
+    LossyDecArgs A{};
+    A.T = b->ts->dev;
+    A.window = b->ts->dev_window;
+    A.bytes = b->d_out;
+    A.blob_off = d_off.as<unsigned long long>();
+    A.blob_len = d_len.as<unsigned int>();
+    A.clip_frame0 = d_c0.as<unsigned long long>();
+    A.clip_frames = d_cn.as<unsigned int>();
+    A.clip_out = d_co.as<unsigned long long>();
+    A.n_clips = (int)b->n_clips;
+    A.channels = b->ch;
+    A.out = dst;
+    A.error = d_err.as<int>();
+    rc = timed_launch(c, "lossy_decode", [&] { return launch_lossy_decode(A, max_hops, c->stream); });
+    if (rc != FLO_OK) return rc;
+    int herr = 0;
+    HIPCHK(c, hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (herr) return fail(c, FLO_ERR_FORMAT, "Failed to deserialize transform frame");
+    return FLO_OK;
+}
+
 extern "C" int flo_decode(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, size_t *n_interleaved,
                           uint32_t *sample_rate, uint8_t *channels) {
     return decode_impl(c, flo, len, pcm, nullptr, n_interleaved, sample_rate, channels);

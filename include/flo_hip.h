@@ -110,6 +110,10 @@ int flo_batch_device_streams(flo_batch *b, const uint8_t **base, const uint64_t 
 /* pack every clip's DATA chunk back to back (16-byte aligned offsets) into a caller-owned device buffer on the ctx
  * stream: the single contiguous payload a rank contributes to the RCCL gather. offsets has n_clips + 1 entries. */
 int flo_batch_pack_streams(flo_batch *b, void *dst_device, size_t dst_cap, uint64_t *offsets);
+/* after sync, lossy batches: decode every clip from its device bitstream into dst (device memory, dst_cap floats).
+ * Clip i's PCM — (frames_i - 1) * 1024 * channels floats, exactly what flo_decode returns for its file — starts at
+ * offsets[i] floats (host array, n_clips entries). The payload never leaves HBM: full-size round-trip checks. */
+int flo_batch_decode(flo_batch *b, float *dst_device, size_t dst_cap_floats, uint64_t *offsets);
 
 /* ---- measurement hooks ----------------------------------------------------------------------------- */
 /* When enabled, every launch of a named kernel on the ctx stream is bracketed by hipEvents on that stream. */
