@@ -311,11 +311,9 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
     const int max_order = A.max_order;
     const int fixed_max = max_order < 4 ? max_order : 4;
     const bool try_lpc = A.level >= 3 && max_order > 4;
-    // contiguous chunk per thread
-    const unsigned int per = (n + kLLThreads - 1) / kLLThreads;
-    const unsigned int i0 = threadIdx.x * per < n ? threadIdx.x * per : n;
-    const unsigned int i1 = i0 + per < n ? i0 + per : n;
-
+    // Thread t takes samples t, t + 256, ...: neighbouring lanes read neighbouring samples (and the same few cache
+    // lines again for the predictor taps), and every statistic is an exact integer sum or maximum, so the partition
+    // does not change any result.
     // ---- sweep 1: autocorrelation lags 0..max_order (lpc.rs:213-221) and fixed-predictor statistics
     {
         long long ac[kMaxOrder + 1];
@@ -323,11 +321,13 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
         unsigned int fm[5];
         for (int l = 0; l <= kMaxOrder; l++) ac[l] = 0;
         for (int o = 0; o < 5; o++) { fs[o] = 0; fm[o] = 0; }
-        for (unsigned int i = i0; i < i1; i++) {
+        for (unsigned int i = threadIdx.x; i < n; i += kLLThreads) {
             const long long si = s[i];
             if (try_lpc) {
                 const int lmax = (int)i < max_order ? (int)i : max_order;
-                for (int l = 0; l <= lmax; l++) ac[l] += si * (long long)s[i - l];
+#pragma unroll
+                for (int l = 0; l <= kMaxOrder; l++)
+                    if (l <= lmax) ac[l] += si * (long long)s[i - l];
             }
             for (int o = 0; o <= fixed_max; o++) {
                 unsigned int a = uabs(fixed_residual(s, i, o));
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
         for (int o = 0; o < 8; o++) { ls[o] = 0; lm[o] = 0; }
         int kf[5];
         for (int o = 0; o < 5; o++) kf[o] = s_k[1 + o];
-        for (unsigned int i = i0; i < i1; i++) {
+        for (unsigned int i = threadIdx.x; i < n; i += kLLThreads) {
             for (int o = 0; o <= fixed_max; o++) {
                 unsigned int q = zigzag(fixed_residual(s, i, o)) >> kf[o];
                 fb[o] += q < 255u ? q : 255u;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
     if (try_lpc) {
         unsigned long long lb[8];
         for (int o = 0; o < 8; o++) lb[o] = 0;
-        for (unsigned int i = i0; i < i1; i++)
+        for (unsigned int i = threadIdx.x; i < n; i += kLLThreads)
             for (int ord = 5; ord <= max_order; ord++) {
                 const int ci = 6 + ord - 5;
                 if (!s_valid[ci]) continue;
@@ -578,51 +578,67 @@ __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
             or_bytes(out, res_pos + 2ull * i, (unsigned int)(unsigned short)(short)s[i], 2);
         return;
     }
-    // Rice: per-thread contiguous chunk, exclusive scan of bit counts, then MSB-first packing (rice.rs:94-114)
-    const unsigned int per = (n + kLLThreads - 1) / kLLThreads;
-    const unsigned int i0 = threadIdx.x * per < n ? threadIdx.x * per : n;
-    const unsigned int i1 = i0 + per < n ? i0 + per : n;
+    // Rice (rice.rs:94-114), in tiles of 256 threads x 16 consecutive samples: a tile spans 16 KiB of the plane that the
+    // workgroup reads completely (every cache line used by neighbouring lanes), each thread counts the bits of its
+    // 16 samples, an exclusive scan places them behind the previous tile, then the bits go out MSB-first.
+    constexpr unsigned int kPer = 16;
     const int k = ch.k;
-    unsigned long long bits = 0;
-    for (unsigned int i = i0; i < i1; i++) {
-        int r = ch.kind == 1 ? fixed_residual(s, i, ch.order) : lpc_residual(s, i, ch.coefs, ch.order, ch.shift);
-        unsigned int q = zigzag(r) >> k;
-        bits += (q < 255u ? q : 255u) + 1u + (unsigned int)k;
-    }
-    sc[threadIdx.x] = bits;
-    __syncthreads();
-    // exclusive scan (Hillis-Steele over 256 entries)
-    for (int d = 1; d < kLLThreads; d <<= 1) {
-        unsigned long long t = threadIdx.x >= (unsigned int)d ? sc[threadIdx.x - d] : 0;
-        __syncthreads();
-        sc[threadIdx.x] += t;
-        __syncthreads();
-    }
-    const unsigned long long start_bit = sc[threadIdx.x] - bits;
-    if (i0 >= i1) return;
-    const unsigned long long abs_bit = 8ull * (unsigned long long)(reinterpret_cast<uintptr_t>(out + res_pos) & 3ull) + start_bit;
+    const unsigned long long bit0 = 8ull * (unsigned long long)(reinterpret_cast<uintptr_t>(out + res_pos) & 3ull);
     unsigned char *base4 = reinterpret_cast<unsigned char *>(reinterpret_cast<uintptr_t>(out + res_pos) & ~(uintptr_t)3);
-    BitSink bs;
-    bs.out = base4;
-    bs.word = abs_bit >> 5;
-    bs.acc = 0;
-    bs.fill = (int)(abs_bit & 31);
-    bs.first = true;
-    for (unsigned int i = i0; i < i1; i++) {
-        int r = ch.kind == 1 ? fixed_residual(s, i, ch.order) : lpc_residual(s, i, ch.coefs, ch.order, ch.shift);
-        unsigned int u = zigzag(r);
-        unsigned int q = u >> k;
-        q = q < 255u ? q : 255u;
-        unsigned int ones = q;
-        while (ones >= 32) {
-            bs.put(0xFFFFFFFFu, 32);
-            ones -= 32;
+    unsigned long long tile_bit = 0;   // bits written by earlier tiles
+    for (unsigned int t0 = 0; t0 < n; t0 += kLLThreads * kPer) {
+        const unsigned int i0 = t0 + threadIdx.x * kPer < n ? t0 + threadIdx.x * kPer : n;
+        const unsigned int i1 = i0 + kPer < n ? i0 + kPer : n;
+        unsigned int u[kPer];
+        unsigned long long bits = 0;
+#pragma unroll
+        for (unsigned int j = 0; j < kPer; j++) {
+            const unsigned int i = i0 + j;
+            u[j] = 0;
+            if (i < i1) {
+                int r = ch.kind == 1 ? fixed_residual(s, i, ch.order) : lpc_residual(s, i, ch.coefs, ch.order, ch.shift);
+                u[j] = zigzag(r);
+                unsigned int q = u[j] >> k;
+                bits += (q < 255u ? q : 255u) + 1u + (unsigned int)k;
+            }
         }
-        // remaining ones, the terminating zero, then k remainder bits
-        if (ones + 1 <= 32) bs.put(ones ? (((1u << ones) - 1u) << 1) : 0u, (int)ones + 1);
-        if (k) bs.put(u & ((1u << k) - 1u), k);
+        __syncthreads();   // the previous tile's readers of sc are done
+        sc[threadIdx.x] = bits;
+        __syncthreads();
+        for (int d = 1; d < kLLThreads; d <<= 1) {   // inclusive scan (Hillis-Steele over 256 entries)
+            unsigned long long t = threadIdx.x >= (unsigned int)d ? sc[threadIdx.x - d] : 0;
+            __syncthreads();
+            sc[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const unsigned long long start_bit = tile_bit + sc[threadIdx.x] - bits;
+        tile_bit += sc[kLLThreads - 1];
+        if (i0 < i1) {
+            const unsigned long long abs_bit = bit0 + start_bit;
+            BitSink bs;
+            bs.out = base4;
+            bs.word = abs_bit >> 5;
+            bs.acc = 0;
+            bs.fill = (int)(abs_bit & 31);
+            bs.first = true;
+#pragma unroll
+            for (unsigned int j = 0; j < kPer; j++) {
+                if (i0 + j < i1) {
+                    unsigned int q = u[j] >> k;
+                    q = q < 255u ? q : 255u;
+                    unsigned int ones = q;
+                    while (ones >= 32) {
+                        bs.put(0xFFFFFFFFu, 32);
+                        ones -= 32;
+                    }
+                    // remaining ones, the terminating zero, then k remainder bits
+                    if (ones + 1 <= 32) bs.put(ones ? (((1u << ones) - 1u) << 1) : 0u, (int)ones + 1);
+                    if (k) bs.put(u[j] & ((1u << k) - 1u), k);
+                }
+            }
+            bs.finish();
+        }
     }
-    bs.finish();
 }
 
 // ------------------------------------------------------------------------------------------------ host side
