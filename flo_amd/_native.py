@@ -21,6 +21,7 @@ EXPORTS = [
     "flo_batch_create", "flo_batch_destroy", "flo_batch_clip_device_ptr", "flo_batch_upload",
     "flo_batch_fill_synthetic", "flo_batch_encode", "flo_batch_sync", "flo_batch_data_bytes", "flo_batch_fetch",
     "flo_batch_device_streams", "flo_batch_pack_streams", "flo_batch_decode",
+    "flo_batch_device_files", "flo_batch_pack_files",
     "flo_ctx_profile_enable", "flo_ctx_profile_query", "flo_ctx_profile_reset", "flo_ctx_force_path", "flo_ctx_stream",
     "flo_mdct_forward", "flo_lossy_analyze", "flo_lossy_quantize", "flo_sparse_pack",
 ]
@@ -75,6 +76,8 @@ def lib():
     L.flo_batch_device_streams.argtypes = [vp, C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint64)),
                                            C.POINTER(C.POINTER(C.c_uint64))]
     L.flo_batch_pack_streams.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64)]
+    L.flo_batch_pack_files.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64)]
+    L.flo_batch_device_files.argtypes = L.flo_batch_device_streams.argtypes
     L.flo_batch_decode.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64)]
     L.flo_ctx_profile_enable.argtypes = [vp, C.c_int]
     L.flo_ctx_profile_query.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]

@@ -269,6 +269,12 @@ class Batch:
         self.ctx._chk(self._L.flo_batch_pack_streams(self._h, dst_ptr, dst_cap, offs))
         return list(offs)
 
+    def pack_files(self, dst_ptr: int, dst_cap: int):
+        """Pack all finished .flo files (empty META) into caller-owned device memory; returns the n_clips + 1 offsets."""
+        offs = (C.c_uint64 * (self.n_clips + 1))()
+        self.ctx._chk(self._L.flo_batch_pack_files(self._h, dst_ptr, dst_cap, offs))
+        return list(offs)
+
     def decode_to(self, dst_ptr: int, dst_cap_floats: int):
         """Decode every clip of an encoded lossy batch into device memory; returns the per-clip float offsets."""
         offs = (C.c_uint64 * max(self.n_clips, 1))()

@@ -1,0 +1,221 @@
+// container_kernels.hip — see container_kernels.hpp. Replaces writer.rs:132-224 (header, TOC) and core/crc32.rs:2-30
+// for DATA chunks that already sit in HBM.
+//
+// CRC32 (IEEE, reflected, init/xorout 0xFFFFFFFF) of a chunk is computed by all 256 threads of a workgroup at once
+// from the linearity of the CRC register over GF(2) (see finish_files_kernel); products x^k * r mod P are 32-step
+// shift-and-xor loops, the per-stripe skip is a table.
+#include "container_kernels.hpp"
+
+#include <cstring>
+
+namespace flo {
+
+constexpr uint32_t kPoly = 0xEDB88320u;
+
+__host__ __device__ inline uint32_t multmodp(uint32_t a, uint32_t b) {   // a(x) * b(x) mod P, reflected bit order
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ kPoly : b >> 1;
+    }
+    return p;
+}
+__host__ __device__ inline uint32_t x8n_modp(unsigned long long n) {   // x^(8 n) mod P
+    uint32_t sq = 0x00800000u;   // x^8 in the reflected representation (x^0 = 0x80000000)
+    uint32_t p = 0x80000000u;
+    while (n) {
+        if (n & 1ull) p = multmodp(sq, p);
+        sq = multmodp(sq, sq);
+        n >>= 1;
+    }
+    return p;
+}
+// x^(8 n) mod P from the table of x^(8 2^j): one product per set bit of n
+__device__ __forceinline__ uint32_t x8n_tab(const unsigned int (&pow2)[40], unsigned long long n) {
+    uint32_t p = 0x80000000u;
+    for (int j = 0; n; j++, n >>= 1)
+        if (n & 1ull) p = multmodp(pow2[j], p);
+    return p;
+}
+uint32_t crc32_combine_host(uint32_t crc1, uint32_t crc2, uint64_t len2) { return multmodp(x8n_modp(len2), crc1) ^ crc2; }
+
+__device__ __forceinline__ void put8(uint8_t *p, unsigned v) { *p = (uint8_t)v; }
+__device__ __forceinline__ void put32(uint8_t *p, uint32_t v) {
+    for (int i = 0; i < 4; i++) p[i] = (uint8_t)(v >> (8 * i));
+}
+__device__ __forceinline__ void put64(uint8_t *p, unsigned long long v) {
+    for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i));
+}
+
+constexpr int kFinThreads = 256;
+constexpr unsigned kBlk = 64;                       // bytes a thread consumes per stripe
+constexpr unsigned kStripe = kFinThreads * kBlk;    // 16 KiB: one coalesced sweep of the workgroup
+
+// The CRC register after a message M from initial value I is (I x^(8n) + M(x) x^32) mod P: linear in I and in M.
+// So the DATA chunk is cut into 64-byte blocks dealt round-robin to the 256 threads (every load of the workgroup is
+// 16 KiB contiguous); a thread carries one register across its blocks, multiplying by x^(8 (16384 - 64)) to skip the
+// other threads' bytes (a 4 x 256 table, like the byte tables), and at the end each register is moved to the end of
+// the message by x^(8 tail) and all are xor-ed together with the contribution of the initial value.
+__global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A) {
+    __shared__ uint32_t tab[4][256];    // slicing-by-4 byte tables
+    __shared__ uint32_t skip[4][256];   // multiplication by x^(8 (kStripe - kBlk))
+    __shared__ uint32_t s_red[kFinThreads / 64];
+    __shared__ uint32_t s_pw[3];
+    __shared__ unsigned long long s_sum[kFinThreads];
+    __shared__ unsigned long long s_smp[kFinThreads];
+    const unsigned clip = blockIdx.x;
+    if (clip >= (unsigned)A.n_clips) return;
+    const unsigned t = threadIdx.x;
+    const unsigned nf = A.clip_frames[clip];
+    const unsigned long long n = A.clip_bytes[clip];
+    const uint8_t *data = A.out + A.data_off[clip];
+    uint8_t *file = A.out + A.data_off[clip] - (74ull + 20ull * nf);
+
+    {   // crc32.rs:2-20 builds the first byte table the same way
+        uint32_t c = t;
+        for (int j = 0; j < 8; j++) c = (c & 1u) ? (c >> 1) ^ kPoly : c >> 1;
+        tab[0][t] = c;
+    }
+    __syncthreads();
+    {
+        uint32_t c = tab[0][t];
+        for (int k = 1; k < 4; k++) {
+            c = tab[0][c & 0xFFu] ^ (c >> 8);
+            tab[k][t] = c;
+        }
+        for (int k = 0; k < 4; k++) skip[k][t] = multmodp(A.skip, t << (8 * k));
+    }
+    const unsigned long long full = n / kStripe;          // complete stripes
+    const unsigned long long rem0 = full * kStripe;       // first byte behind them
+    const unsigned rem = (unsigned)(n - rem0);
+    const unsigned nb = rem / kBlk, last = rem % kBlk;
+    // three per-clip powers, each by the first lane of a different wave: x^(8 rem), x^(8 last), 0xFFFFFFFF x^(8 n)
+    if (t == 0) s_pw[0] = x8n_tab(A.x8pow2, rem);
+    if (t == 64) s_pw[1] = x8n_tab(A.x8pow2, last);
+    if (t == 128) s_pw[2] = multmodp(x8n_tab(A.x8pow2, n), 0xFFFFFFFFu);   // the initial register, carried through n bytes
+    __syncthreads();
+    auto eat = [&](uint32_t reg, const uint8_t *p, unsigned bytes) {   // bytes is a multiple of 4, p 4-byte aligned
+        for (unsigned i = 0; i < bytes; i += 4) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(p + i) ^ reg;
+            reg = tab[3][w & 0xFFu] ^ tab[2][(w >> 8) & 0xFFu] ^ tab[1][(w >> 16) & 0xFFu] ^ tab[0][w >> 24];
+        }
+        return reg;
+    };
+    uint32_t acc = 0;
+    if (full) {
+        uint32_t reg = 0;
+        const uint8_t *p = data + (unsigned long long)t * kBlk;
+        for (unsigned long long sidx = 0; sidx < full; sidx++, p += kStripe) {
+            reg = skip[0][reg & 0xFFu] ^ skip[1][(reg >> 8) & 0xFFu] ^ skip[2][(reg >> 16) & 0xFFu] ^ skip[3][reg >> 24];
+            const uint4 a = *reinterpret_cast<const uint4 *>(p), b = *reinterpret_cast<const uint4 *>(p + 16),
+                        c = *reinterpret_cast<const uint4 *>(p + 32), d = *reinterpret_cast<const uint4 *>(p + 48);
+            const uint32_t w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t v = w[i] ^ reg;
+                reg = tab[3][v & 0xFFu] ^ tab[2][(v >> 8) & 0xFFu] ^ tab[1][(v >> 16) & 0xFFu] ^ tab[0][v >> 24];
+            }
+        }
+        // the register now stands behind this thread's block of the last complete stripe
+        // ... and moves to the end of the message: x^(8 (64 (255 - t) + rem))
+        acc = multmodp(multmodp(A.blk_pow[kFinThreads - 1 - t], s_pw[0]), reg);
+    }
+    {   // the incomplete stripe: one 64-byte block per thread, then the last < 64 bytes on thread 0
+        if (t < nb) {
+            const uint32_t reg = eat(0, data + rem0 + (unsigned long long)t * kBlk, kBlk);
+            acc ^= multmodp(multmodp(A.blk_pow[nb - 1 - t], s_pw[1]), reg);
+        }
+        if (t == 0) {
+            uint32_t reg = 0;
+            const uint8_t *p = data + rem0 + (unsigned long long)nb * kBlk;
+            for (unsigned i = 0; i < last; i++) reg = tab[0][(reg ^ p[i]) & 0xFFu] ^ (reg >> 8);
+            acc ^= reg;
+            acc ^= s_pw[2];
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_down(acc, d);
+    if ((t & 63) == 0) s_red[t >> 6] = acc;
+
+    // TOC: thread t owns a contiguous run of frames; byte offsets and sample counts by a block scan of the run sums
+    const unsigned per = (nf + kFinThreads - 1) / kFinThreads;
+    const unsigned f0 = t * per < nf ? t * per : nf, f1 = f0 + per < nf ? f0 + per : nf;
+    const unsigned long long fb = A.clip_frame0[clip];
+    unsigned long long bytes = 0, smp = 0;
+    for (unsigned f = f0; f < f1; f++) {
+        bytes += A.frame_size[fb + f];
+        smp += A.frame_samples ? A.frame_samples[fb + f] : A.const_samples;
+    }
+    s_sum[t] = bytes;
+    s_smp[t] = smp;
+    __syncthreads();
+    for (int d = 1; d < kFinThreads; d <<= 1) {   // inclusive Hillis-Steele scans
+        const unsigned long long a = t >= (unsigned)d ? s_sum[t - d] : 0, b = t >= (unsigned)d ? s_smp[t - d] : 0;
+        __syncthreads();
+        s_sum[t] += a;
+        s_smp[t] += b;
+        __syncthreads();
+    }
+    {
+        unsigned long long off = s_sum[t] - bytes, cum = s_smp[t] - smp;
+        uint8_t *toc = file + 70 + 4;
+        for (unsigned f = f0; f < f1; f++) {   // writer.rs:193-224: index, byte offset, size, timestamp in ms
+            uint8_t *e = toc + 20ull * f;
+            const unsigned fs = A.frame_size[fb + f];
+            put32(e, f);
+            put64(e + 4, off);
+            put32(e + 12, fs);
+            put32(e + 16, (uint32_t)(cum * 1000ull / (unsigned long long)A.sample_rate));
+            off += fs;
+            cum += A.frame_samples ? A.frame_samples[fb + f] : A.const_samples;
+        }
+    }
+    if (t == 0) {
+        uint32_t r = 0;
+        for (int k = 0; k < kFinThreads / 64; k++) r ^= s_red[k];
+        const uint32_t crc = ~r;
+        if (A.crc_out) A.crc_out[clip] = crc;
+        // header (writer.rs:132-191)
+        uint8_t *p = file;
+        p[0] = 'F'; p[1] = 'L'; p[2] = 'O'; p[3] = '!';
+        put8(p + 4, 1);    // version 1.2 (core/types.rs:12-13)
+        put8(p + 5, 2);
+        put8(p + 6, A.flags & 0xFF);
+        put8(p + 7, A.flags >> 8);
+        put32(p + 8, A.sample_rate);
+        put8(p + 12, A.channels);
+        put8(p + 13, A.bit_depth);
+        put64(p + 14, s_smp[kFinThreads - 1]);   // total_samples = sum of frame_samples
+        put8(p + 22, A.level);
+        put8(p + 23, 0); put8(p + 24, 0); put8(p + 25, 0);
+        put32(p + 26, crc);
+        put64(p + 30, 66);
+        put64(p + 38, 4ull + 20ull * nf);
+        put64(p + 46, n);
+        put64(p + 54, 0);
+        put64(p + 62, 0);    // meta_size: patched by whoever appends a META chunk
+        put32(p + 70, nf);
+    }
+}
+
+int launch_finish_files(FinishArgs A, hipStream_t s) {
+    if (!A.n_clips) return 0;
+    static unsigned int pow2[40], blk[256], skip = 0;
+    if (!skip) {
+        uint32_t p = 0x00800000u;   // x^8
+        for (int j = 0; j < 40; j++, p = multmodp(p, p)) pow2[j] = p;
+        for (int i = 0; i < 256; i++) blk[i] = x8n_modp(64ull * i);
+        skip = x8n_modp(kStripe - kBlk);
+    }
+    memcpy(A.x8pow2, pow2, sizeof pow2);
+    memcpy(A.blk_pow, blk, sizeof blk);
+    A.skip = skip;
+    hipLaunchKernelGGL(finish_files_kernel, dim3((unsigned)A.n_clips), dim3(kFinThreads), 0, s, A);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace flo

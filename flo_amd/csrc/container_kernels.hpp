@@ -1,0 +1,34 @@
+// container_kernels.hpp — on-device .flo framing: header, TOC and CRC32 of every clip of a batch, written
+// in front of the DATA chunk the encode kernels left in HBM, so that [file_off, file_off + head + data) is a finished
+// .flo file (META, if any, is appended by the caller, who then patches meta_size).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace flo {
+
+struct FinishArgs {
+    uint8_t *out;                           // the batch's output buffer
+    const unsigned long long *data_off;     // [n_clips] DATA chunk start (16-byte aligned); the file starts 74 + 20 frames before
+    const unsigned long long *clip_bytes;   // [n_clips] DATA chunk length (written by the encode kernels)
+    const unsigned long long *clip_frame0;  // [n_clips] first frame of the clip among all frames
+    const unsigned int *clip_frames;        // [n_clips] frames per clip
+    const unsigned int *frame_size;         // [total_frames] bytes per frame
+    const unsigned int *frame_samples;      // [total_frames] or null: every frame holds const_samples
+    unsigned int const_samples;
+    unsigned int sample_rate;
+    unsigned short flags;                   // header flags (writer.rs:64-68)
+    unsigned char channels, bit_depth, level;
+    int n_clips;
+    unsigned int *crc_out;                  // [n_clips] CRC32 of each DATA chunk (also in the header)
+    // powers of x modulo the CRC polynomial (reflected), filled in by launch_finish_files
+    unsigned int x8pow2[40];                // x^(8 * 2^j)
+    unsigned int skip;                      // x^(8 * (16384 - 64)): from one 64-byte block of a thread to its next
+    unsigned int blk_pow[256];              // x^(8 * 64 * i)
+};
+
+int launch_finish_files(FinishArgs A, hipStream_t s);
+// host mirror of the device CRC combination (x^(8 len) mod P in the reflected domain), used by the CPU self-check
+uint32_t crc32_combine_host(uint32_t crc1, uint32_t crc2, uint64_t len2);
+
+}  // namespace flo

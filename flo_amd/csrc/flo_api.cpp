@@ -12,6 +12,7 @@
 
 #include "../../include/flo_hip.h"
 #include "container.hpp"
+#include "container_kernels.hpp"
 #include "decode_kernels.hpp"
 #include "lossless_kernels.hpp"
 #include "lossy_kernels.hpp"
@@ -250,6 +251,7 @@ struct flo_batch {
     TableSet *ts = nullptr;
     // plan (host)
     std::vector<uint64_t> n_il, clip_off, clip_nsf, clip_frame0, out_off, out_cap;
+    std::vector<uint64_t> file_off, h_file_bytes;   // finished file = [file_off, file_off + 74 + 20 frames + DATA)
     std::vector<uint32_t> hops;
     uint64_t total_frames = 0, total_floats = 0, out_bytes = 0;
     // device
@@ -259,6 +261,7 @@ struct flo_batch {
     uint8_t *d_out = nullptr;
     uint32_t *d_frame_size = nullptr;
     uint64_t *d_clip_bytes = nullptr;
+    uint32_t *d_crc = nullptr;
     float *d_at = nullptr, *d_sprev = nullptr;
     uint8_t *d_slots = nullptr;
     uint64_t *d_frame_off = nullptr;
@@ -284,7 +287,7 @@ extern "C" void flo_batch_destroy(flo_batch *b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
-    void *ptrs[] = {b->d_pcm, b->d_plan, b->d_hops, b->d_out, b->d_frame_size, b->d_clip_bytes, b->d_at,
+    void *ptrs[] = {b->d_pcm, b->d_plan, b->d_hops, b->d_out, b->d_frame_size, b->d_clip_bytes, b->d_crc, b->d_at,
                     b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw, b->d_pack_plan};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -340,6 +343,7 @@ extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size
         b->clip_frame0.resize(n_clips);
         b->out_off.resize(n_clips);
         b->out_cap.resize(n_clips);
+        b->file_off.resize(n_clips);
         uint64_t f = 0, o = 0;
         const size_t mfb = lossy_max_frame_bytes(ch);
         for (size_t i = 0; i < n_clips; i++) {
@@ -347,7 +351,11 @@ extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size
             b->hops[i] = (uint32_t)h;
             b->clip_frame0[i] = f;
             f += h;
+            // header + TOC of the finished file sit right in front of the (16-byte aligned) DATA chunk
+            const uint64_t head = 74 + 20 * h;
+            o += (head + 15) & ~(uint64_t)15;
             b->out_off[i] = o;
+            b->file_off[i] = o - head;
             b->out_cap[i] = ((h * mfb + 64) + 15) & ~(uint64_t)15;
             o += b->out_cap[i];
         }
@@ -365,6 +373,7 @@ extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size
         BCHK(hipMalloc(&b->d_out, b->out_bytes + 64));
         BCHK(hipMalloc(&b->d_frame_size, (b->total_frames + 1) * 4));
         BCHK(hipMalloc(&b->d_clip_bytes, (n_clips + 1) * 8));
+        BCHK(hipMalloc(&b->d_crc, (n_clips + 1) * 4));
         if (n_clips) {
             BCHK(hipMemcpy(b->d_plan, plan.data(), plan.size() * 8, hipMemcpyHostToDevice));
             BCHK(hipMemcpy(b->d_hops, b->hops.data(), n_clips * 4, hipMemcpyHostToDevice));
@@ -471,33 +480,49 @@ extern "C" int flo_batch_encode(flo_batch *b, int which) {
     if (!b->total_frames) return FLO_OK;
     if (which == 0) which = c->force_path;
     if (which == 0) which = (b->n_clips * b->ch >= 512) ? (b->ch == 2 ? 3 : 1) : 2;
-    if (which == 1) {
+    int rc;
+    if (which == 1 || (which == 3 && b->ch != 2)) {
 #ifdef FLO_STAMPS
         if (!b->d_stamps) HIPCHK(c, hipMalloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
 #endif
         LossyArgs A = make_args(b);
-        return timed_launch(c, "lossy_chain", [&] { return launch_lossy_chain(A, c->stream); });
-    }
-    if (which == 3) {   // stereo pipeline: two channel waves + one packer wave per clip
+        rc = timed_launch(c, "lossy_chain", [&] { return launch_lossy_chain(A, c->stream); });
+    } else if (which == 3) {   // stereo pipeline: two channel waves + one packer wave per clip
         LossyArgs A = make_args(b);
-        if (b->ch != 2) return timed_launch(c, "lossy_chain", [&] { return launch_lossy_chain(A, c->stream); });
-        return timed_launch(c, "lossy_chain3", [&] { return launch_lossy_chain3(A, c->stream); });
+        rc = timed_launch(c, "lossy_chain3", [&] { return launch_lossy_chain3(A, c->stream); });
+    } else {   // frame-parallel form
+        if (!b->d_at) {
+            size_t n = (size_t)b->total_frames * b->ch * 32 * sizeof(float);
+            HIPCHK(c, hipMalloc(&b->d_at, n));
+            HIPCHK(c, hipMalloc(&b->d_sprev, n));
+            HIPCHK(c, hipMalloc(&b->d_slots, (size_t)b->total_frames * kFrameCap));
+            HIPCHK(c, hipMalloc(&b->d_frame_off, (size_t)(b->total_frames + 1) * 8));
+        }
+        LossyArgs A = make_args(b);
+        if ((rc = timed_launch(c, "lossy_bands", [&] { return launch_lossy_frames_pass(A, 1, c->stream); })) != FLO_OK) return rc;
+        if ((rc = timed_launch(c, "lossy_scan", [&] { return launch_lossy_scan(A, c->stream); })) != FLO_OK) return rc;
+        if ((rc = timed_launch(c, "lossy_frames", [&] { return launch_lossy_frames_pass(A, 2, c->stream); })) != FLO_OK) return rc;
+        rc = timed_launch(c, "lossy_compact", [&] { return launch_lossy_compact(A, c->stream); });
     }
-    // frame-parallel form
-    if (!b->d_at) {
-        size_t n = (size_t)b->total_frames * b->ch * 32 * sizeof(float);
-        HIPCHK(c, hipMalloc(&b->d_at, n));
-        HIPCHK(c, hipMalloc(&b->d_sprev, n));
-        HIPCHK(c, hipMalloc(&b->d_slots, (size_t)b->total_frames * kFrameCap));
-        HIPCHK(c, hipMalloc(&b->d_frame_off, (size_t)(b->total_frames + 1) * 8));
-    }
-    LossyArgs A = make_args(b);
-    int rc;
-    if ((rc = timed_launch(c, "lossy_bands", [&] { return launch_lossy_frames_pass(A, 1, c->stream); })) != FLO_OK) return rc;
-    if ((rc = timed_launch(c, "lossy_scan", [&] { return launch_lossy_scan(A, c->stream); })) != FLO_OK) return rc;
-    if ((rc = timed_launch(c, "lossy_frames", [&] { return launch_lossy_frames_pass(A, 2, c->stream); })) != FLO_OK) return rc;
-    if ((rc = timed_launch(c, "lossy_compact", [&] { return launch_lossy_compact(A, c->stream); })) != FLO_OK) return rc;
-    return FLO_OK;
+    if (rc != FLO_OK) return rc;
+    // header, TOC and CRC32 of every clip, in front of its DATA chunk (writer.rs:132-224; encoder.rs:229-238 parameters)
+    FinishArgs F{};
+    F.out = b->d_out;
+    F.data_off = (const unsigned long long *)(b->d_plan + 3 * b->n_clips);
+    F.clip_bytes = (const unsigned long long *)b->d_clip_bytes;
+    F.clip_frame0 = (const unsigned long long *)(b->d_plan + 2 * b->n_clips);
+    F.clip_frames = b->d_hops;
+    F.frame_size = b->d_frame_size;
+    F.frame_samples = nullptr;
+    F.const_samples = 1024;
+    F.sample_rate = b->sr;
+    F.flags = (unsigned short)(0x01 | ((unsigned)b->ts->host.q_level << 8));
+    F.channels = b->ch;
+    F.bit_depth = 16;
+    F.level = 5;
+    F.n_clips = (int)b->n_clips;
+    F.crc_out = b->d_crc;
+    return timed_launch(c, "finish_files", [&] { return launch_finish_files(F, c->stream); });
 }
 
 extern "C" int flo_batch_sync(flo_batch *b) {
@@ -507,12 +532,12 @@ extern "C" int flo_batch_sync(flo_batch *b) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (b->encoded && !b->synced) {
         if (b->mode == FLO_MODE_LOSSY) {
+            // only the per-clip sizes come back; frame sizes stay on the device (the TOC is written there) and are
+            // fetched on demand by the few host paths that want them
             b->h_clip_bytes.assign(b->n_clips, 0);
-            b->h_frame_size.assign(b->total_frames, 0);
-            if (b->n_clips && b->total_frames) {
+            b->h_frame_size.clear();
+            if (b->n_clips && b->total_frames)
                 HIPCHK(c, hipMemcpy(b->h_clip_bytes.data(), b->d_clip_bytes, b->n_clips * 8, hipMemcpyDeviceToHost));
-                HIPCHK(c, hipMemcpy(b->h_frame_size.data(), b->d_frame_size, b->total_frames * 4, hipMemcpyDeviceToHost));
-            }
             for (size_t i = 0; i < b->n_clips; i++)
                 if (b->h_clip_bytes[i] > b->out_cap[i]) return fail(c, FLO_ERR_DEVICE, "bitstream overran its buffer");
 #ifdef FLO_STAMPS
@@ -565,16 +590,32 @@ extern "C" int flo_batch_device_streams(flo_batch *b, const uint8_t **base, cons
     return lossless_device_streams(b->ll, base, offsets, sizes) == 0 ? FLO_OK : FLO_ERR_STATE;
 }
 
-// Pack every clip's DATA chunk into dst (device memory owned by the caller, e.g. a torch tensor), clip i at
-// offsets[i] (16-byte aligned, offsets[n_clips] = total). Asynchronous on the ctx stream.
-extern "C" int flo_batch_pack_streams(flo_batch *b, void *dst_device, size_t dst_cap, uint64_t *offsets) {
+// Finished files (header + TOC + DATA, no META) as they sit in HBM after flo_batch_sync.
+extern "C" int flo_batch_device_files(flo_batch *b, const uint8_t **base, const uint64_t **offsets, const uint64_t **sizes) {
+    if (!b) return FLO_ERR_ARG;
+    if (!b->synced) return fail(b->ctx, FLO_ERR_STATE, "call flo_batch_encode + flo_batch_sync first");
+    if (b->mode == FLO_MODE_LOSSY) {
+        if (b->h_file_bytes.size() != b->n_clips) b->h_file_bytes.resize(b->n_clips);
+        for (size_t i = 0; i < b->n_clips; i++) b->h_file_bytes[i] = 74 + 20 * (uint64_t)b->hops[i] + b->h_clip_bytes[i];
+        if (base) *base = b->d_out;
+        if (offsets) *offsets = b->file_off.data();
+        if (sizes) *sizes = b->h_file_bytes.data();
+        return FLO_OK;
+    }
+    return lossless_device_files(b->ll, base, offsets, sizes) == 0 ? FLO_OK : FLO_ERR_STATE;
+}
+
+// Pack every clip's DATA chunk (files = false) or finished .flo file without META (files = true) into dst (device
+// memory owned by the caller, e.g. a torch tensor), clip i at offsets[i] (16-byte aligned, offsets[n_clips] = total).
+// Asynchronous on the ctx stream.
+static int pack_impl(flo_batch *b, bool files, void *dst_device, size_t dst_cap, uint64_t *offsets) {
     if (!b || !offsets || (!dst_device && dst_cap)) return FLO_ERR_ARG;
     flo_ctx *c = b->ctx;
     if (!b->synced) return fail(c, FLO_ERR_STATE, "call flo_batch_encode + flo_batch_sync first");
     HIPCHK(c, hipSetDevice(c->device));
     const uint8_t *base;
     const uint64_t *offs, *sizes;
-    int rc = flo_batch_device_streams(b, &base, &offs, &sizes);
+    int rc = files ? flo_batch_device_files(b, &base, &offs, &sizes) : flo_batch_device_streams(b, &base, &offs, &sizes);
     if (rc != FLO_OK) return rc;
     uint64_t pos = 0;
     for (size_t i = 0; i < b->n_clips; i++) {
@@ -598,6 +639,12 @@ extern "C" int flo_batch_pack_streams(flo_batch *b, void *dst_device, size_t dst
         return launch_pack_streams(base, dp, dp + b->n_clips, dp + 2 * b->n_clips, (int)b->n_clips, (uint8_t *)dst_device, c->stream);
     });
 }
+extern "C" int flo_batch_pack_streams(flo_batch *b, void *dst_device, size_t dst_cap, uint64_t *offsets) {
+    return pack_impl(b, false, dst_device, dst_cap, offsets);
+}
+extern "C" int flo_batch_pack_files(flo_batch *b, void *dst_device, size_t dst_cap, uint64_t *offsets) {
+    return pack_impl(b, true, dst_device, dst_cap, offsets);
+}
 
 extern "C" int flo_batch_fetch(flo_batch *b, size_t clip, const uint8_t *meta, size_t meta_len, uint8_t **out,
                                size_t *out_len) {
@@ -610,16 +657,20 @@ extern "C" int flo_batch_fetch(flo_batch *b, size_t clip, const uint8_t *meta, s
         int rc = lossless_fetch(b->ll, clip, b->bit_depth, meta, meta_len, out, out_len, err);
         return rc == 0 ? FLO_OK : fail(c, FLO_ERR_DEVICE, "lossless fetch: " + err);
     }
-    const size_t n = (size_t)b->h_clip_bytes[clip];
-    std::vector<uint8_t> data(n);
-    if (n) HIPCHK(c, hipMemcpy(data.data(), b->d_out + b->out_off[clip], n, hipMemcpyDeviceToHost));
-    const uint32_t hops = b->hops[clip];
-    std::vector<uint32_t> fsamp(hops, 1024);
-    FileParams fp{b->sr, b->ch, 16, 5, true, b->ts->host.q_level};  // encoder.rs:229-238
-    uint8_t *f = assemble_file(fp, data.data(), n, b->h_frame_size.data() + b->clip_frame0[clip], fsamp.data(), hops,
-                               meta, meta_len, out_len);
+    // the file was finished on the device: copy it, append META and patch meta_size (header bytes 62..69)
+    const size_t head = 74 + 20 * (size_t)b->hops[clip];
+    const size_t n = head + (size_t)b->h_clip_bytes[clip];
+    uint8_t *f = (uint8_t *)malloc(n + meta_len ? n + meta_len : 1);
     if (!f) return fail(c, FLO_ERR_NOMEM, "malloc failed");
+    hipError_t e = hipMemcpy(f, b->d_out + b->file_off[clip], n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        free(f);
+        return fail(c, FLO_ERR_DEVICE, std::string("fetch: ") + hipGetErrorString(e));
+    }
+    if (meta_len) memcpy(f + n, meta, meta_len);
+    for (int i = 0; i < 8; i++) f[62 + i] = (uint8_t)((uint64_t)meta_len >> (8 * i));
     *out = f;
+    *out_len = n + meta_len;
     return FLO_OK;
 }
 
@@ -967,6 +1018,11 @@ extern "C" int flo_batch_decode(flo_batch *b, float *dst, size_t dst_cap, uint64
     if (b->mode != FLO_MODE_LOSSY) return fail(c, FLO_ERR_ARG, "flo_batch_decode handles lossy batches");
     if (!b->synced) return fail(c, FLO_ERR_STATE, "call flo_batch_encode + flo_batch_sync first");
     HIPCHK(c, hipSetDevice(c->device));
+    if (b->h_frame_size.size() != b->total_frames) {
+        b->h_frame_size.assign(b->total_frames, 0);
+        if (b->total_frames)
+            HIPCHK(c, hipMemcpy(b->h_frame_size.data(), b->d_frame_size, b->total_frames * 4, hipMemcpyDeviceToHost));
+    }
     std::vector<unsigned long long> blob_off(b->total_frames), c0(b->n_clips), co(b->n_clips);
     std::vector<unsigned int> blob_len(b->total_frames), cn(b->n_clips);
     uint64_t total = 0;

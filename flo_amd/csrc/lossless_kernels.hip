@@ -24,6 +24,8 @@
 #include "container.hpp"
 #include "lossless_kernels.hpp"
 
+#include "container_kernels.hpp"
+
 namespace flo {
 
 constexpr int kLLThreads = 256;
@@ -78,6 +80,7 @@ struct LLArgs {
     unsigned long long *clip_bytes;
     unsigned int n_clips;
     unsigned char *out;
+    unsigned int *frame_size;              // [n_frames] bytes of each frame (for the TOC)
 };
 
 // ------------------------------------------------------------------------------------------------ helpers
@@ -490,6 +493,7 @@ __global__ void ll_layout_kernel(LLArgs A) {
             pos += 4 + psize;
         }
         fo.size = (unsigned int)(pos - off);
+        A.frame_size[f] = fo.size;
         off = pos;
     }
     A.clip_bytes[clip] = off;
@@ -650,7 +654,7 @@ struct LosslessPlan {
     const float *d_pcm = nullptr;
     std::vector<LLFrame> frames;
     std::vector<uint32_t> clip_first_frame;
-    std::vector<uint64_t> clip_out_off, clip_out_cap;
+    std::vector<uint64_t> clip_out_off, clip_out_cap, clip_file_off;
     uint64_t out_bytes = 0, plane_ints = 0;
     size_t n_chans = 0;
     // device
@@ -659,11 +663,12 @@ struct LosslessPlan {
     LLChan *d_chans = nullptr;
     int *d_planes = nullptr;
     uint32_t *d_cff = nullptr;
-    uint64_t *d_coo = nullptr, *d_clip_bytes = nullptr;
+    uint64_t *d_coo = nullptr, *d_clip_bytes = nullptr, *d_cf0 = nullptr;
+    uint32_t *d_fsize = nullptr, *d_fsamp = nullptr, *d_cfn = nullptr, *d_crc = nullptr;
     uint8_t *d_out = nullptr;
     // host results
     std::vector<LLFrameOut> h_fout;
-    std::vector<uint64_t> h_clip_bytes;
+    std::vector<uint64_t> h_clip_bytes, h_file_bytes;
     hipStream_t stream = nullptr;
 };
 
@@ -674,7 +679,8 @@ static int level_to_order(int level) {  // encoder.rs:289-302
 
 void lossless_plan_destroy(LosslessPlan *p) {
     if (!p) return;
-    void *ptrs[] = {p->d_frames, p->d_fout, p->d_chans, p->d_planes, p->d_cff, p->d_coo, p->d_clip_bytes, p->d_out};
+    void *ptrs[] = {p->d_frames, p->d_fout, p->d_chans, p->d_planes, p->d_cff, p->d_coo, p->d_clip_bytes, p->d_out,
+                    p->d_cf0, p->d_fsize, p->d_fsamp, p->d_cfn, p->d_crc};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -692,6 +698,7 @@ LosslessPlan *lossless_plan_create(const std::vector<uint64_t> &n_il, const std:
     p->clip_first_frame.resize(p->n_clips + 1);
     p->clip_out_off.resize(p->n_clips);
     p->clip_out_cap.resize(p->n_clips);
+    p->clip_file_off.resize(p->n_clips);
     const uint64_t spf = sr;
     uint64_t out = 0, planes = 0;
     for (size_t i = 0; i < p->n_clips; i++) {
@@ -714,7 +721,11 @@ LosslessPlan *lossless_plan_create(const std::vector<uint64_t> &n_il, const std:
             cap += 6 + (uint64_t)ch * (4 + 56 + 2ull * fr.plane_stride);
             p->frames.push_back(fr);
         }
+        // header + TOC of the finished file sit right in front of the (16-byte aligned) DATA chunk
+        const uint64_t head = 74 + 20 * nf;
+        out += (head + 15) & ~15ull;
         p->clip_out_off[i] = out;
+        p->clip_file_off[i] = out - head;
         p->clip_out_cap[i] = (cap + 8 + 15) & ~15ull;
         out += p->clip_out_cap[i];
     }
@@ -741,6 +752,23 @@ LosslessPlan *lossless_plan_create(const std::vector<uint64_t> &n_il, const std:
     if (nf) LCHK(hipMemcpy(p->d_frames, p->frames.data(), nf * sizeof(LLFrame), hipMemcpyHostToDevice));
     LCHK(hipMemcpy(p->d_cff, p->clip_first_frame.data(), (p->n_clips + 1) * 4, hipMemcpyHostToDevice));
     if (p->n_clips) LCHK(hipMemcpy(p->d_coo, p->clip_out_off.data(), p->n_clips * 8, hipMemcpyHostToDevice));
+    {   // what the on-device file assembly needs: frames per clip, first frame, samples per frame
+        std::vector<uint64_t> cf0(p->n_clips + 1);
+        std::vector<uint32_t> cfn(p->n_clips + 1), fsamp(nf + 1);
+        for (size_t i = 0; i < p->n_clips; i++) {
+            cf0[i] = p->clip_first_frame[i];
+            cfn[i] = p->clip_first_frame[i + 1] - p->clip_first_frame[i];
+        }
+        for (size_t f = 0; f < nf; f++) fsamp[f] = p->frames[f].frame_samples;
+        LCHK(hipMalloc(&p->d_cf0, cf0.size() * 8));
+        LCHK(hipMalloc(&p->d_cfn, cfn.size() * 4));
+        LCHK(hipMalloc(&p->d_fsamp, fsamp.size() * 4));
+        LCHK(hipMalloc(&p->d_fsize, (nf + 1) * 4));
+        LCHK(hipMalloc(&p->d_crc, (p->n_clips + 1) * 4));
+        LCHK(hipMemcpy(p->d_cf0, cf0.data(), cf0.size() * 8, hipMemcpyHostToDevice));
+        LCHK(hipMemcpy(p->d_cfn, cfn.data(), cfn.size() * 4, hipMemcpyHostToDevice));
+        LCHK(hipMemcpy(p->d_fsamp, fsamp.data(), fsamp.size() * 4, hipMemcpyHostToDevice));
+    }
 #undef LCHK
     return p;
 }
@@ -758,7 +786,6 @@ int lossless_encode_launch(LosslessPlan *p, hipStream_t s, int profile, std::str
         err = hipGetErrorString(e);
         return -1;
     }
-    if (nf == 0) return 0;
     LLArgs A{};
     A.pcm = p->d_pcm;
     A.planes = p->d_planes;
@@ -774,12 +801,36 @@ int lossless_encode_launch(LosslessPlan *p, hipStream_t s, int profile, std::str
     A.clip_bytes = (unsigned long long *)p->d_clip_bytes;
     A.n_clips = (unsigned)p->n_clips;
     A.out = p->d_out;
-    hipLaunchKernelGGL(ll_prepare_kernel, dim3(nf), dim3(kLLThreads), 0, s, A);
-    hipLaunchKernelGGL(ll_analyze_kernel, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A);
-    hipLaunchKernelGGL(ll_layout_kernel, dim3((A.n_clips + 63) / 64), dim3(64), 0, s, A);
-    hipLaunchKernelGGL(ll_pack_kernel, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A);
+    A.frame_size = p->d_fsize;
+    if (nf) {
+        hipLaunchKernelGGL(ll_prepare_kernel, dim3(nf), dim3(kLLThreads), 0, s, A);
+        hipLaunchKernelGGL(ll_analyze_kernel, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A);
+        hipLaunchKernelGGL(ll_layout_kernel, dim3((A.n_clips + 63) / 64), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(ll_pack_kernel, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A);
+    }
     if ((e = hipGetLastError()) != hipSuccess) {
         err = hipGetErrorString(e);
+        return -1;
+    }
+    // header, TOC and CRC32 in front of every DATA chunk (writer.rs:132-224; encoder.rs:36-44 parameters)
+    FinishArgs F{};
+    F.out = p->d_out;
+    F.data_off = (const unsigned long long *)p->d_coo;
+    F.clip_bytes = (const unsigned long long *)p->d_clip_bytes;
+    F.clip_frame0 = (const unsigned long long *)p->d_cf0;
+    F.clip_frames = p->d_cfn;
+    F.frame_size = p->d_fsize;
+    F.frame_samples = p->d_fsamp;
+    F.const_samples = 0;
+    F.sample_rate = p->sr;
+    F.flags = 0;
+    F.channels = p->ch;
+    F.bit_depth = 16;   // echoed from the caller when the file is fetched
+    F.level = p->level;
+    F.n_clips = (int)p->n_clips;
+    F.crc_out = p->d_crc;
+    if (launch_finish_files(F, s) != 0) {
+        err = "finish_files launch failed";
         return -1;
     }
     return 0;
@@ -819,28 +870,37 @@ int lossless_device_streams(LosslessPlan *p, const uint8_t **base, const uint64_
     return 0;
 }
 
+int lossless_device_files(LosslessPlan *p, const uint8_t **base, const uint64_t **offsets, const uint64_t **sizes) {
+    p->h_file_bytes.resize(p->n_clips);
+    for (size_t i = 0; i < p->n_clips; i++)
+        p->h_file_bytes[i] = 74 + 20 * (uint64_t)(p->clip_first_frame[i + 1] - p->clip_first_frame[i]) + p->h_clip_bytes[i];
+    if (base) *base = p->d_out;
+    if (offsets) *offsets = p->clip_file_off.data();
+    if (sizes) *sizes = p->h_file_bytes.data();
+    return 0;
+}
+
 int lossless_fetch(LosslessPlan *p, size_t clip, uint8_t bit_depth, const uint8_t *meta, size_t meta_len, uint8_t **out,
                    size_t *out_len, std::string &err) {
-    const size_t n = (size_t)p->h_clip_bytes[clip];
-    std::vector<uint8_t> data(n);
-    hipError_t e;
-    if (n && (e = hipMemcpy(data.data(), p->d_out + p->clip_out_off[clip], n, hipMemcpyDeviceToHost)) != hipSuccess) {
-        err = hipGetErrorString(e);
-        return -1;
-    }
-    const uint32_t f0 = p->clip_first_frame[clip], f1 = p->clip_first_frame[clip + 1];
-    std::vector<uint32_t> fsz(f1 - f0), fsamp(f1 - f0);
-    for (uint32_t f = f0; f < f1; f++) {
-        fsz[f - f0] = p->h_fout[f].size;
-        fsamp[f - f0] = p->frames[f].frame_samples;
-    }
-    FileParams fp{p->sr, p->ch, bit_depth, p->level, false, 0};  // encoder.rs:36-44
-    uint8_t *buf = assemble_file(fp, data.data(), n, fsz.data(), fsamp.data(), fsz.size(), meta, meta_len, out_len);
-    if (!buf) {
+    // the file was finished on the device: copy it, append META, patch bit_depth (header byte 13) and meta_size (62..69)
+    const size_t nf = p->clip_first_frame[clip + 1] - p->clip_first_frame[clip];
+    const size_t n = 74 + 20 * nf + (size_t)p->h_clip_bytes[clip];
+    uint8_t *f = (uint8_t *)malloc(n + meta_len);
+    if (!f) {
         err = "malloc failed";
         return -1;
     }
-    *out = buf;
+    hipError_t e = hipMemcpy(f, p->d_out + p->clip_file_off[clip], n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        free(f);
+        err = hipGetErrorString(e);
+        return -1;
+    }
+    if (meta_len) memcpy(f + n, meta, meta_len);
+    f[13] = bit_depth;
+    for (int i = 0; i < 8; i++) f[62 + i] = (uint8_t)((uint64_t)meta_len >> (8 * i));
+    *out = f;
+    *out_len = n + meta_len;
     return 0;
 }
 

@@ -21,6 +21,7 @@ int lossless_encode_launch(LosslessPlan *p, hipStream_t s, int profile, std::str
 int lossless_collect(LosslessPlan *p, std::string &err);
 uint64_t lossless_total_bytes(const LosslessPlan *p);
 int lossless_device_streams(LosslessPlan *p, const uint8_t **base, const uint64_t **offsets, const uint64_t **sizes);
+int lossless_device_files(LosslessPlan *p, const uint8_t **base, const uint64_t **offsets, const uint64_t **sizes);
 int lossless_fetch(LosslessPlan *p, size_t clip, uint8_t bit_depth, const uint8_t *meta, size_t meta_len, uint8_t **out,
                    size_t *out_len, std::string &err);
 

@@ -59,7 +59,8 @@ def gather_payloads(dist, payload, rank: int, world: int, dst: int = 0):
 
 
 class BitstreamGather:
-    """Per-step gather used by bench.py: pack this rank's DATA chunks into one device tensor, then gather to rank 0."""
+    """Per-step gather used by bench.py: pack this rank's finished .flo files (header, TOC and CRC are made on the
+    device) into one device tensor, then gather to rank 0."""
 
     def __init__(self, ctx, batch, dist, rank, world, local_rank):
         import torch
@@ -67,13 +68,15 @@ class BitstreamGather:
         self.device = torch.device("cuda", local_rank)
         self.buf = None
         self.last_total = 0
+        # header + TOC of every file: 74 + 20 bytes per frame; a frame is at most 1 s (lossless) or 1024 samples (lossy)
+        self.head_bytes = sum(74 + 20 * (n // (1024 * 1) + 2) for n in batch.n_interleaved)
 
     def run(self):
         import torch
-        need = self.batch.data_bytes() + 16 * self.batch.n_clips + 64
+        need = self.batch.data_bytes() + self.head_bytes + 16 * self.batch.n_clips + 64
         if self.buf is None or self.buf.numel() < need:
             self.buf = torch.empty(int(need * 1.25), dtype=torch.uint8, device=self.device)
-        offs = self.batch.pack_streams(self.buf.data_ptr(), self.buf.numel())
+        offs = self.batch.pack_files(self.buf.data_ptr(), self.buf.numel())
         self.batch.sync()
         payload = self.buf[: offs[-1]]
         got, sizes = gather_payloads(self.dist, payload, self.rank, self.world, 0)

@@ -110,6 +110,13 @@ int flo_batch_device_streams(flo_batch *b, const uint8_t **base, const uint64_t 
 /* pack every clip's DATA chunk back to back (16-byte aligned offsets) into a caller-owned device buffer on the ctx
  * stream: the single contiguous payload a rank contributes to the RCCL gather. offsets has n_clips + 1 entries. */
 int flo_batch_pack_streams(flo_batch *b, void *dst_device, size_t dst_cap, uint64_t *offsets);
+/* The same for FINISHED FILES: after flo_batch_sync every clip's header (version 1.2, CRC32 of DATA, sizes), TOC and
+ * DATA sit contiguously in HBM — writer.rs:132-224 and core/crc32.rs done on the device — i.e. a complete .flo file
+ * with an empty META chunk. device_files exposes them in place; pack_files copies them back to back (16-byte aligned
+ * offsets) into caller-owned device memory: the payload of the multi-GPU gather. (bit_depth in the header is 16;
+ * flo_batch_fetch / flo_encode_lossless patch the caller's value and the META size when they copy a file out.) */
+int flo_batch_device_files(flo_batch *b, const uint8_t **base, const uint64_t **offsets, const uint64_t **sizes);
+int flo_batch_pack_files(flo_batch *b, void *dst_device, size_t dst_cap, uint64_t *offsets);
 /* after sync, lossy batches: decode every clip from its device bitstream into dst (device memory, dst_cap floats).
  * Clip i's PCM — (frames_i - 1) * 1024 * channels floats, exactly what flo_decode returns for its file — starts at
  * offsets[i] floats (host array, n_clips entries). The payload never leaves HBM: full-size round-trip checks. */

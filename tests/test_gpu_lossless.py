@@ -149,3 +149,26 @@ def test_lossless_roundtrip_at_scale(ctx):
         assert (back == want).all()
         assert enc == O.encode_lossless(pcm, 44100, 2, 16, 5)
     b.close()
+
+
+def test_finished_files_in_hbm_equal_the_oracle_files(ctx):
+    # header, TOC and CRC32 are made on the device: the packed files must be the oracle's files byte for byte
+    import torch
+    import flo_amd
+    sr = 44100
+    clips = [signals.music_like(sr, n, 2, seed=n) for n in (0, 1, 30000, 44100, 100000)]
+    b = flo_amd.Batch(ctx, flo_amd.MODE_LOSSLESS, [c.size for c in clips], sr, 2, 5)
+    for i, c in enumerate(clips):
+        b.upload(i, c)
+    b.encode(0)
+    b.sync()
+    buf = torch.empty(b.data_bytes() + len(clips) * 256 + 1024, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    offs = b.pack_files(buf.data_ptr(), buf.numel())
+    b.sync()
+    host = buf.cpu().numpy()
+    for i, c in enumerate(clips):
+        want = O.encode_lossless(c, sr, 2, 16, 5)
+        assert host[offs[i]:offs[i] + len(want)].tobytes() == want
+        assert b.fetch(i, b"meta!") == O.encode_lossless(c, sr, 2, 16, 5, b"meta!")
+    b.close()

@@ -267,6 +267,15 @@ def test_pack_streams_and_single_rank_rccl_gather(ctx):
     for i in range(3):
         f = flofile.parse(b.fetch(i))
         assert host[offs[i]:offs[i] + f.data_size].tobytes() == f.data and offs[i] % 16 == 0
+    # the finished files (header, TOC, CRC made on the device) pack the same way and equal what fetch returns
+    fbuf = torch.empty(b.data_bytes() + 3 * (74 + 20 * 64 + 16) + 64, dtype=torch.uint8, device="cuda:0")
+    foffs = b.pack_files(fbuf.data_ptr(), fbuf.numel())
+    b.sync()
+    fhost = fbuf.cpu().numpy()
+    for i in range(3):
+        whole = b.fetch(i)
+        assert fhost[foffs[i]:foffs[i] + len(whole)].tobytes() == whole and foffs[i] % 16 == 0
+        assert flofile.parse(whole).crc_valid
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
