@@ -41,7 +41,6 @@ __device__ __forceinline__ uint32_t x8n_tab(const unsigned int (&pow2)[40], unsi
         if (n & 1ull) p = multmodp(pow2[j], p);
     return p;
 }
-uint32_t crc32_combine_host(uint32_t crc1, uint32_t crc2, uint64_t len2) { return multmodp(x8n_modp(len2), crc1) ^ crc2; }
 
 __device__ __forceinline__ void put8(uint8_t *p, unsigned v) { *p = (uint8_t)v; }
 __device__ __forceinline__ void put32(uint8_t *p, uint32_t v) {

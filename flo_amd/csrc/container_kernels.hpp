@@ -28,7 +28,5 @@ struct FinishArgs {
 };
 
 int launch_finish_files(FinishArgs A, hipStream_t s);
-// host mirror of the device CRC combination (x^(8 len) mod P in the reflected domain), used by the CPU self-check
-uint32_t crc32_combine_host(uint32_t crc1, uint32_t crc2, uint64_t len2);
 
 }  // namespace flo
