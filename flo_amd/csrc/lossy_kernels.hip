@@ -442,8 +442,22 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
     }
     __syncthreads();
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cl = wv / 3;                  // clip slot inside the workgroup
-    const int w = wv % 3;                   // 0, 1: channel waves; 2: packer
+    // Role of this wave: 0, 1 = channel waves, 2 = packer. A packer wave issues about a third more instructions per
+    // frame than a channel wave, and waves land on the four SIMDs round-robin by index; with five clips (15 waves)
+    // the roles are dealt so that every SIMD carries three channel waves and one packer, or two packers and one
+    // channel wave on the SIMD that hosts only three waves (0x... tables below: 4 bits per wave).
+    int cl, w;
+    if (clips_per_wg == 5) {
+        //            wave:  0 1 2 3 4 5 6 7 8 9 10 11 12 13 14
+        // role              C C C P C C C P C C  C  C  P  P  P
+        const unsigned long long role_tab = 0x222101021012010ull;   // channel index (0/1) or 2
+        const unsigned long long clip_tab = 0x432443312210100ull;   // clip slot
+        w = (int)((role_tab >> (4 * wv)) & 15ull);
+        cl = (int)((clip_tab >> (4 * wv)) & 15ull);
+    } else {
+        cl = wv / 3;
+        w = wv % 3;
+    }
     const unsigned clip = blockIdx.x * (unsigned)clips_per_wg + (unsigned)cl;
     if (clip >= (unsigned)A.n_clips) return;
     Clip3Lds &cs = *reinterpret_cast<Clip3Lds *>(lds_raw + kPackBytes + (size_t)cl * sizeof(Clip3Lds));
