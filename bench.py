@@ -193,6 +193,17 @@ def main():
             "sample": f"{args.cpu_clips} of the same synthetic 10 s stereo clips, q=0.55, oracle (C restatement of libflo, "
                       f"single thread like the reference; the Rust toolchain is not available here), {d2:.1f} s",
         }
+        # SURVEY 8d also asks for "one clip per thread on all host cores": the same clips again, one oracle call per
+        # pool thread (ctypes releases the GIL during the call)
+        from concurrent.futures import ThreadPoolExecutor
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        reps = max(1, min(4, (2 * cores + args.cpu_clips - 1) // args.cpu_clips))
+        t3 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as pool:
+            list(pool.map(lambda c: len(O.encode_lossy(c, sr, ch, args.quality)), clips * reps))
+        d3 = time.perf_counter() - t3
+        out["cpu_baseline"]["all_cores"] = {"value": round(reps * args.cpu_clips * n_il / d3 / 1e6, 3), "unit": "Msamples/s",
+                                            "cores": cores, "sample": f"{reps * args.cpu_clips} clips, one per pool thread, {d3:.1f} s"}
     print(json.dumps(out))
     batch.close()
     ctx.close()

@@ -314,9 +314,34 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
     const int max_order = A.max_order;
     const int fixed_max = max_order < 4 ? max_order : 4;
     const bool try_lpc = A.level >= 3 && max_order > 4;
-    // Thread t takes samples t, t + 256, ...: neighbouring lanes read neighbouring samples (and the same few cache
-    // lines again for the predictor taps), and every statistic is an exact integer sum or maximum, so the partition
-    // does not change any result.
+    // The plane is walked in tiles of 256 threads x 16 consecutive samples. A thread keeps its 16 samples and the 12
+    // before them in registers (kWin), so every predictor tap of every candidate is a register operand: the plane is
+    // read once per sweep instead of once per tap. Every statistic is an exact integer sum or maximum, so how the
+    // samples are dealt to threads cannot change a result.
+    constexpr int kRun = 16, kHist = kMaxOrder, kWin = kRun + kHist;
+    const unsigned int tile = kLLThreads * kRun;
+    auto load_window = [&](unsigned int i0, int (&w)[kWin]) {
+#pragma unroll
+        for (int j = 0; j < kWin; j++) {
+            const long long idx = (long long)i0 - kHist + j;
+            w[j] = (idx >= 0 && idx < (long long)n) ? s[idx] : 0;
+        }
+    };
+    // residual of the fixed predictor `o` at position i = i0 + j (lpc.rs:301-359; positions below the order use order i)
+    auto fixed_res = [&](const int (&w)[kWin], unsigned int i, int j, int o) {
+        const int oo = o < (int)i ? o : (int)i;
+        const long long x0 = w[kHist + j], x1 = w[kHist + j - 1], x2 = w[kHist + j - 2], x3 = w[kHist + j - 3], x4 = w[kHist + j - 4];
+        long long v;
+        switch (oo) {
+            case 0: v = x0; break;
+            case 1: v = x0 - x1; break;
+            case 2: v = x0 - 2ll * x1 + x2; break;
+            case 3: v = x0 - 3ll * x1 + 3ll * x2 - x3; break;
+            default: v = x0 - 4ll * x1 + 6ll * x2 - 4ll * x3 + x4; break;
+        }
+        return (int)(unsigned int)(unsigned long long)v;
+    };
+
     // ---- sweep 1: autocorrelation lags 0..max_order (lpc.rs:213-221) and fixed-predictor statistics
     {
         long long ac[kMaxOrder + 1];
@@ -324,18 +349,28 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
         unsigned int fm[5];
         for (int l = 0; l <= kMaxOrder; l++) ac[l] = 0;
         for (int o = 0; o < 5; o++) { fs[o] = 0; fm[o] = 0; }
-        for (unsigned int i = threadIdx.x; i < n; i += kLLThreads) {
-            const long long si = s[i];
-            if (try_lpc) {
-                const int lmax = (int)i < max_order ? (int)i : max_order;
+        for (unsigned int t0 = 0; t0 < n; t0 += tile) {
+            const unsigned int i0 = t0 + threadIdx.x * kRun;
+            if (i0 >= n) continue;
+            int w[kWin];
+            load_window(i0, w);
 #pragma unroll
-                for (int l = 0; l <= kMaxOrder; l++)
-                    if (l <= lmax) ac[l] += si * (long long)s[i - l];
-            }
-            for (int o = 0; o <= fixed_max; o++) {
-                unsigned int a = uabs(fixed_residual(s, i, o));
-                fs[o] += a;
-                fm[o] = fm[o] > a ? fm[o] : a;
+            for (int j = 0; j < kRun; j++) {
+                const unsigned int i = i0 + j;
+                if (i >= n) break;
+                if (try_lpc) {
+                    const long long si = w[kHist + j];
+#pragma unroll
+                    for (int l = 0; l <= kMaxOrder; l++)
+                        if (l <= max_order && (unsigned int)l <= i) ac[l] += si * (long long)w[kHist + j - l];
+                }
+#pragma unroll
+                for (int o = 0; o < 5; o++)
+                    if (o <= fixed_max) {
+                        const unsigned int a = uabs(fixed_res(w, i, j, o));
+                        fs[o] += a;
+                        fm[o] = fm[o] > a ? fm[o] : a;
+                    }
             }
         }
         if (try_lpc)
@@ -370,6 +405,17 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
     }
     __syncthreads();
 
+    // LPC residual of order ORD at position i = i0 + j from the window (lpc.rs:279-298)
+    auto lpc_res = [&](const int (&w)[kWin], unsigned int i, int j, int ord, const int *coef, int shift) {
+        if (i < (unsigned int)ord) return w[kHist + j];
+        long long pred = 0;
+#pragma unroll
+        for (int q = 0; q < kMaxOrder; q++)
+            if (q < ord) pred += (long long)coef[q] * (long long)w[kHist + j - 1 - q];
+        pred >>= shift;
+        return (int)((unsigned int)w[kHist + j] - (unsigned int)(int)pred);
+    };
+
     // ---- sweep 2: code lengths of the fixed candidates, statistics of the LPC candidates
     {
         unsigned long long fb[5];
@@ -379,17 +425,37 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
         for (int o = 0; o < 8; o++) { ls[o] = 0; lm[o] = 0; }
         int kf[5];
         for (int o = 0; o < 5; o++) kf[o] = s_k[1 + o];
-        for (unsigned int i = threadIdx.x; i < n; i += kLLThreads) {
-            for (int o = 0; o <= fixed_max; o++) {
-                unsigned int q = zigzag(fixed_residual(s, i, o)) >> kf[o];
-                fb[o] += q < 255u ? q : 255u;
-            }
+        for (unsigned int t0 = 0; t0 < n; t0 += tile) {
+            const unsigned int i0 = t0 + threadIdx.x * kRun;
+            if (i0 >= n) continue;
+            int w[kWin];
+            load_window(i0, w);
+#pragma unroll
+            for (int o = 0; o < 5; o++)
+                if (o <= fixed_max) {
+#pragma unroll
+                    for (int j = 0; j < kRun; j++)
+                        if (i0 + j < n) {
+                            unsigned int q = zigzag(fixed_res(w, i0 + j, j, o)) >> kf[o];
+                            fb[o] += q < 255u ? q : 255u;
+                        }
+                }
             if (try_lpc) {
-                for (int ord = 5; ord <= max_order; ord++) {
-                    if (!s_valid[6 + ord - 5]) continue;
-                    unsigned int a = uabs(lpc_residual(s, i, s_coef[ord - 5], ord, s_shift[ord - 5]));
-                    ls[ord - 5] += a;
-                    lm[ord - 5] = lm[ord - 5] > a ? lm[ord - 5] : a;
+#pragma unroll
+                for (int oi = 0; oi < 8; oi++) {
+                    const int ord = 5 + oi;
+                    if (ord > max_order || !s_valid[6 + oi]) continue;   // uniform across the block
+                    int coef[kMaxOrder];
+#pragma unroll
+                    for (int q = 0; q < kMaxOrder; q++) coef[q] = q < ord ? s_coef[oi][q] : 0;
+                    const int sh = s_shift[oi];
+#pragma unroll
+                    for (int j = 0; j < kRun; j++)
+                        if (i0 + j < n) {
+                            const unsigned int a = uabs(lpc_res(w, i0 + j, j, ord, coef, sh));
+                            ls[oi] += a;
+                            lm[oi] = lm[oi] > a ? lm[oi] : a;
+                        }
                 }
             }
         }
@@ -414,13 +480,27 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
     if (try_lpc) {
         unsigned long long lb[8];
         for (int o = 0; o < 8; o++) lb[o] = 0;
-        for (unsigned int i = threadIdx.x; i < n; i += kLLThreads)
-            for (int ord = 5; ord <= max_order; ord++) {
-                const int ci = 6 + ord - 5;
-                if (!s_valid[ci]) continue;
-                unsigned int q = zigzag(lpc_residual(s, i, s_coef[ord - 5], ord, s_shift[ord - 5])) >> s_k[ci];
-                lb[ord - 5] += q < 255u ? q : 255u;
+        for (unsigned int t0 = 0; t0 < n; t0 += tile) {
+            const unsigned int i0 = t0 + threadIdx.x * kRun;
+            if (i0 >= n) continue;
+            int w[kWin];
+            load_window(i0, w);
+#pragma unroll
+            for (int oi = 0; oi < 8; oi++) {
+                const int ord = 5 + oi;
+                if (ord > max_order || !s_valid[6 + oi]) continue;
+                int coef[kMaxOrder];
+#pragma unroll
+                for (int q = 0; q < kMaxOrder; q++) coef[q] = q < ord ? s_coef[oi][q] : 0;
+                const int sh = s_shift[oi], kk = s_k[6 + oi];
+#pragma unroll
+                for (int j = 0; j < kRun; j++)
+                    if (i0 + j < n) {
+                        unsigned int q = zigzag(lpc_res(w, i0 + j, j, ord, coef, sh)) >> kk;
+                        lb[oi] += q < 255u ? q : 255u;
+                    }
             }
+        }
         for (int ord = 5; ord <= max_order; ord++) {
             const int ci = 6 + ord - 5;
             if (!s_valid[ci]) continue;
