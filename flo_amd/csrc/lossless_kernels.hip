@@ -675,15 +675,48 @@ __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
         const unsigned int i1 = i0 + kPer < n ? i0 + kPer : n;
         unsigned int u[kPer];
         unsigned long long bits = 0;
+        if (i0 < i1) {
+            // the thread's 16 samples and the 12 before them, once; every predictor tap is then a register operand
+            int w[kPer + kMaxOrder];
 #pragma unroll
-        for (unsigned int j = 0; j < kPer; j++) {
-            const unsigned int i = i0 + j;
-            u[j] = 0;
-            if (i < i1) {
-                int r = ch.kind == 1 ? fixed_residual(s, i, ch.order) : lpc_residual(s, i, ch.coefs, ch.order, ch.shift);
-                u[j] = zigzag(r);
-                unsigned int q = u[j] >> k;
-                bits += (q < 255u ? q : 255u) + 1u + (unsigned int)k;
+            for (int j = 0; j < (int)kPer + kMaxOrder; j++) {
+                const long long idx = (long long)i0 - kMaxOrder + j;
+                w[j] = (idx >= 0 && idx < (long long)n) ? s[idx] : 0;
+            }
+#pragma unroll
+            for (unsigned int j = 0; j < kPer; j++) {
+                const unsigned int i = i0 + j;
+                u[j] = 0;
+                if (i < i1) {
+                    const int x0 = w[kMaxOrder + j];
+                    int r;
+                    if (ch.kind == 1) {   // fixed predictor (lpc.rs:301-359); positions below the order use order i
+                        const int oo = ch.order < (int)i ? ch.order : (int)i;
+                        const long long x1 = w[kMaxOrder + j - 1], x2 = w[kMaxOrder + j - 2], x3 = w[kMaxOrder + j - 3],
+                                        x4 = w[kMaxOrder + j - 4];
+                        long long v;
+                        switch (oo) {
+                            case 0: v = x0; break;
+                            case 1: v = (long long)x0 - x1; break;
+                            case 2: v = (long long)x0 - 2ll * x1 + x2; break;
+                            case 3: v = (long long)x0 - 3ll * x1 + 3ll * x2 - x3; break;
+                            default: v = (long long)x0 - 4ll * x1 + 6ll * x2 - 4ll * x3 + x4; break;
+                        }
+                        r = (int)(unsigned int)(unsigned long long)v;
+                    } else if (i < (unsigned int)ch.order) {   // LPC warm-up copies the samples (lpc.rs:279-298)
+                        r = x0;
+                    } else {
+                        long long pred = 0;
+#pragma unroll
+                        for (int q = 0; q < kMaxOrder; q++)
+                            if (q < ch.order) pred += (long long)ch.coefs[q] * (long long)w[kMaxOrder + j - 1 - q];
+                        pred >>= ch.shift;
+                        r = (int)((unsigned int)x0 - (unsigned int)(int)pred);
+                    }
+                    u[j] = zigzag(r);
+                    unsigned int q = u[j] >> k;
+                    bits += (q < 255u ? q : 255u) + 1u + (unsigned int)k;
+                }
             }
         }
         __syncthreads();   // the previous tile's readers of sc are done
