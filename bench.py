@@ -25,6 +25,26 @@ ALG_BYTES_PER_SAMPLE = 4.0 + 2.0 + 50.0 / 1024.0   # f32 in + i16 out + 25 u16 s
 HBM_PEAK_GBS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def host_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box shows every
+    CPU of the host but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                     # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = fh.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, p = int(fq.read()), int(fp.read())
+                if q > 0:
+                    n = min(n, max(1, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def hbm_traffic(kname, args):
     """HBM bytes per launch of the dominant kernel from the PMC passes of profiles/collect.sh (rocprofv3 cannot run
     inside this process; the summary is of this same command and workload). None when there is no summary for the
@@ -55,6 +75,7 @@ def main():
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 two-wave chain kernel, 2 frame-parallel kernels, 3 three-wave chain kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-clip", action="store_true")
+    ap.add_argument("--no-lossless", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=200)
     args = ap.parse_args()
 
@@ -180,6 +201,25 @@ def main():
                                    "realtime_factor": round(n180 / d1 / (sr * ch), 1)}
         b1.close()
 
+    if not args.no_lossless and world == 1:
+        # BASELINE configs[4] shape (96 kHz stereo, level 5) as a batch; bit-exactness is the tests' business, this is
+        # the throughput of the ALPC + Rice kernels (no roofline claim: bound by 64-bit multiply-adds)
+        lsr, lsec, lclips = 96000, 10, 128
+        bl = flo_amd.Batch(ctx, flo_amd.MODE_LOSSLESS, [lsr * lsec * ch] * lclips, lsr, ch, 5)
+        bl.fill_synthetic(seed=0xF10A0D10, clip_id0=20_000_000)
+        for _ in range(2):
+            bl.encode(0)
+            bl.sync()
+        reps = 5
+        t4 = time.perf_counter()
+        for _ in range(reps):
+            bl.encode(0)
+            bl.sync()
+        d4 = (time.perf_counter() - t4) / reps
+        out["lossless_96k"] = {"workload": f"{lclips} x {lsec} s 96 kHz stereo clips, lossless level 5 (BASELINE configs[4] shape)",
+                               "value": round(lsr * lsec * ch * lclips / d4 / 1e6, 1), "unit": "Msamples/s", "ms": round(d4 * 1e3, 3),
+                               "compressed_bytes": bl.data_bytes()}
+        bl.close()
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as O
         clips = [O.synth_clip(n_sf, ch, 0xF10A0D10, i) for i in range(args.cpu_clips)]
@@ -196,7 +236,7 @@ def main():
         # SURVEY 8d also asks for "one clip per thread on all host cores": the same clips again, one oracle call per
         # pool thread (ctypes releases the GIL during the call)
         from concurrent.futures import ThreadPoolExecutor
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = host_cores()
         reps = max(1, min(4, (2 * cores + args.cpu_clips - 1) // args.cpu_clips))
         t3 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=cores) as pool:
