@@ -55,24 +55,34 @@ constexpr unsigned kBlk = 64;                       // bytes a thread consumes p
 constexpr unsigned kStripe = kFinThreads * kBlk;    // 16 KiB: one coalesced sweep of the workgroup
 
 // The CRC register after a message M from initial value I is (I x^(8n) + M(x) x^32) mod P: linear in I and in M.
-// So the DATA chunk is cut into 64-byte blocks dealt round-robin to the 256 threads (every load of the workgroup is
-// 16 KiB contiguous); a thread carries one register across its blocks, multiplying by x^(8 (16384 - 64)) to skip the
-// other threads' bytes (a 4 x 256 table, like the byte tables), and at the end each register is moved to the end of
-// the message by x^(8 tail) and all are xor-ed together with the contribution of the initial value.
-__global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A) {
+// So a slice of the DATA chunk is cut into 64-byte blocks dealt round-robin to the 256 threads (every load of the
+// workgroup is 16 KiB contiguous); a thread carries one register across its blocks, multiplying by
+// x^(8 (16384 - 64)) to skip the other threads' bytes (a 4 x 256 table, like the byte tables), and at the end each
+// register is moved to the end of the slice by x^(8 tail) and all are xor-ed together. A clip is cut into `parts`
+// slices (one workgroup each, so that a single long clip still fills the chip); finish_files_kernel moves the slice
+// registers to the end of the message and adds the contribution of the initial value.
+__device__ __forceinline__ unsigned long long slice_bytes(unsigned long long n, unsigned parts) {
+    unsigned long long s = (n + parts - 1) / parts;
+    return (s + kStripe - 1) / kStripe * kStripe;
+}
+
+__global__ __launch_bounds__(kFinThreads) void crc_slices_kernel(FinishArgs A) {
     __shared__ uint32_t tab[4][256];    // slicing-by-4 byte tables
     __shared__ uint32_t skip[4][256];   // multiplication by x^(8 (kStripe - kBlk))
     __shared__ uint32_t s_red[kFinThreads / 64];
-    __shared__ uint32_t s_pw[3];
-    __shared__ unsigned long long s_sum[kFinThreads];
-    __shared__ unsigned long long s_smp[kFinThreads];
-    const unsigned clip = blockIdx.x;
+    __shared__ uint32_t s_pw[2];
+    const unsigned clip = blockIdx.y, part = blockIdx.x;
     if (clip >= (unsigned)A.n_clips) return;
     const unsigned t = threadIdx.x;
-    const unsigned nf = A.clip_frames[clip];
-    const unsigned long long n = A.clip_bytes[clip];
-    const uint8_t *data = A.out + A.data_off[clip];
-    uint8_t *file = A.out + A.data_off[clip] - (74ull + 20ull * nf);
+    const unsigned long long total = A.clip_bytes[clip];
+    const unsigned long long S = slice_bytes(total, A.parts);
+    const unsigned long long beg = (unsigned long long)part * S < total ? (unsigned long long)part * S : total;
+    const unsigned long long n = beg + S < total ? S : total - beg;
+    if (n == 0) {
+        if (t == 0) A.part_reg[(unsigned long long)clip * A.parts + part] = 0;
+        return;
+    }
+    const uint8_t *data = A.out + A.data_off[clip] + beg;
 
     {   // crc32.rs:2-20 builds the first byte table the same way
         uint32_t c = t;
@@ -92,10 +102,9 @@ __global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A)
     const unsigned long long rem0 = full * kStripe;       // first byte behind them
     const unsigned rem = (unsigned)(n - rem0);
     const unsigned nb = rem / kBlk, last = rem % kBlk;
-    // three per-clip powers, each by the first lane of a different wave: x^(8 rem), x^(8 last), 0xFFFFFFFF x^(8 n)
+    // two per-slice powers, each by the first lane of a different wave: x^(8 rem), x^(8 last)
     if (t == 0) s_pw[0] = x8n_tab(A.x8pow2, rem);
     if (t == 64) s_pw[1] = x8n_tab(A.x8pow2, last);
-    if (t == 128) s_pw[2] = multmodp(x8n_tab(A.x8pow2, n), 0xFFFFFFFFu);   // the initial register, carried through n bytes
     __syncthreads();
     auto eat = [&](uint32_t reg, const uint8_t *p, unsigned bytes) {   // bytes is a multiple of 4, p 4-byte aligned
         for (unsigned i = 0; i < bytes; i += 4) {
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A)
             }
         }
         // the register now stands behind this thread's block of the last complete stripe
-        // ... and moves to the end of the message: x^(8 (64 (255 - t) + rem))
+        // ... and moves to the end of the slice: x^(8 (64 (255 - t) + rem))
         acc = multmodp(multmodp(A.blk_pow[kFinThreads - 1 - t], s_pw[0]), reg);
     }
     {   // the incomplete stripe: one 64-byte block per thread, then the last < 64 bytes on thread 0
@@ -133,7 +142,39 @@ __global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A)
             const uint8_t *p = data + rem0 + (unsigned long long)nb * kBlk;
             for (unsigned i = 0; i < last; i++) reg = tab[0][(reg ^ p[i]) & 0xFFu] ^ (reg >> 8);
             acc ^= reg;
-            acc ^= s_pw[2];
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_down(acc, d);
+    if ((t & 63) == 0) s_red[t >> 6] = acc;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t r = 0;
+        for (int k = 0; k < kFinThreads / 64; k++) r ^= s_red[k];
+        A.part_reg[(unsigned long long)clip * A.parts + part] = r;
+    }
+}
+
+__global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A) {
+    __shared__ uint32_t s_red[kFinThreads / 64];
+    __shared__ unsigned long long s_sum[kFinThreads];
+    __shared__ unsigned long long s_smp[kFinThreads];
+    const unsigned clip = blockIdx.x;
+    if (clip >= (unsigned)A.n_clips) return;
+    const unsigned t = threadIdx.x;
+    const unsigned nf = A.clip_frames[clip];
+    const unsigned long long n = A.clip_bytes[clip];
+    uint8_t *file = A.out + A.data_off[clip] - (74ull + 20ull * nf);
+
+    // slice registers -> end of the message; thread `parts` adds the initial register carried through all n bytes
+    uint32_t acc = 0;
+    {
+        const unsigned long long S = slice_bytes(n, A.parts);
+        if (t < A.parts) {
+            const unsigned long long end = (unsigned long long)(t + 1) * S < n ? (unsigned long long)(t + 1) * S : n;
+            const unsigned long long beg = (unsigned long long)t * S < n ? (unsigned long long)t * S : n;
+            if (end > beg) acc = multmodp(x8n_tab(A.x8pow2, n - end), A.part_reg[(unsigned long long)clip * A.parts + t]);
+        } else if (t == A.parts) {
+            acc = multmodp(x8n_tab(A.x8pow2, n), 0xFFFFFFFFu);
         }
     }
     for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_down(acc, d);
@@ -202,6 +243,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A)
 
 int launch_finish_files(FinishArgs A, hipStream_t s) {
     if (!A.n_clips) return 0;
+    if (A.parts < 1 || A.parts > 128 || !A.part_reg) return -1;
     static unsigned int pow2[40], blk[256], skip = 0;
     if (!skip) {
         uint32_t p = 0x00800000u;   // x^8
@@ -212,6 +254,7 @@ int launch_finish_files(FinishArgs A, hipStream_t s) {
     memcpy(A.x8pow2, pow2, sizeof pow2);
     memcpy(A.blk_pow, blk, sizeof blk);
     A.skip = skip;
+    hipLaunchKernelGGL(crc_slices_kernel, dim3(A.parts, (unsigned)A.n_clips), dim3(kFinThreads), 0, s, A);
     hipLaunchKernelGGL(finish_files_kernel, dim3((unsigned)A.n_clips), dim3(kFinThreads), 0, s, A);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

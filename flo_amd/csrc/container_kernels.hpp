@@ -21,6 +21,8 @@ struct FinishArgs {
     unsigned char channels, bit_depth, level;
     int n_clips;
     unsigned int *crc_out;                  // [n_clips] CRC32 of each DATA chunk (also in the header)
+    unsigned int parts;                     // slices per clip for the CRC (1..128): few long clips still fill the chip
+    unsigned int *part_reg;                 // [n_clips * parts] scratch: CRC register of every slice
     // powers of x modulo the CRC polynomial (reflected), filled in by launch_finish_files
     unsigned int x8pow2[40];                // x^(8 * 2^j)
     unsigned int skip;                      // x^(8 * (16384 - 64)): from one 64-byte block of a thread to its next
@@ -28,5 +30,11 @@ struct FinishArgs {
 };
 
 int launch_finish_files(FinishArgs A, hipStream_t s);
+// slices per clip so that about two thousand workgroups run, at most 128
+inline unsigned finish_parts_for(size_t n_clips) {
+    if (n_clips >= 1024) return 1;
+    size_t p = (2048 + n_clips - 1) / (n_clips ? n_clips : 1);
+    return (unsigned)(p > 128 ? 128 : p);
+}
 
 }  // namespace flo

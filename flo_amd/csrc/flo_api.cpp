@@ -261,7 +261,7 @@ struct flo_batch {
     uint8_t *d_out = nullptr;
     uint32_t *d_frame_size = nullptr;
     uint64_t *d_clip_bytes = nullptr;
-    uint32_t *d_crc = nullptr;
+    uint32_t *d_crc = nullptr, *d_part = nullptr;
     float *d_at = nullptr, *d_sprev = nullptr;
     uint8_t *d_slots = nullptr;
     uint64_t *d_frame_off = nullptr;
@@ -287,7 +287,7 @@ extern "C" void flo_batch_destroy(flo_batch *b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
-    void *ptrs[] = {b->d_pcm, b->d_plan, b->d_hops, b->d_out, b->d_frame_size, b->d_clip_bytes, b->d_crc, b->d_at,
+    void *ptrs[] = {b->d_pcm, b->d_plan, b->d_hops, b->d_out, b->d_frame_size, b->d_clip_bytes, b->d_crc, b->d_part, b->d_at,
                     b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw, b->d_pack_plan};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -374,6 +374,7 @@ extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size
         BCHK(hipMalloc(&b->d_frame_size, (b->total_frames + 1) * 4));
         BCHK(hipMalloc(&b->d_clip_bytes, (n_clips + 1) * 8));
         BCHK(hipMalloc(&b->d_crc, (n_clips + 1) * 4));
+        BCHK(hipMalloc(&b->d_part, (n_clips * finish_parts_for(n_clips) + 1) * 4));
         if (n_clips) {
             BCHK(hipMemcpy(b->d_plan, plan.data(), plan.size() * 8, hipMemcpyHostToDevice));
             BCHK(hipMemcpy(b->d_hops, b->hops.data(), n_clips * 4, hipMemcpyHostToDevice));
@@ -522,6 +523,8 @@ extern "C" int flo_batch_encode(flo_batch *b, int which) {
     F.level = 5;
     F.n_clips = (int)b->n_clips;
     F.crc_out = b->d_crc;
+    F.parts = finish_parts_for(b->n_clips);
+    F.part_reg = b->d_part;
     return timed_launch(c, "finish_files", [&] { return launch_finish_files(F, c->stream); });
 }
 

@@ -777,7 +777,7 @@ struct LosslessPlan {
     int *d_planes = nullptr;
     uint32_t *d_cff = nullptr;
     uint64_t *d_coo = nullptr, *d_clip_bytes = nullptr, *d_cf0 = nullptr;
-    uint32_t *d_fsize = nullptr, *d_fsamp = nullptr, *d_cfn = nullptr, *d_crc = nullptr;
+    uint32_t *d_fsize = nullptr, *d_fsamp = nullptr, *d_cfn = nullptr, *d_crc = nullptr, *d_part = nullptr;
     uint8_t *d_out = nullptr;
     // host results
     std::vector<LLFrameOut> h_fout;
@@ -793,7 +793,7 @@ static int level_to_order(int level) {  // encoder.rs:289-302
 void lossless_plan_destroy(LosslessPlan *p) {
     if (!p) return;
     void *ptrs[] = {p->d_frames, p->d_fout, p->d_chans, p->d_planes, p->d_cff, p->d_coo, p->d_clip_bytes, p->d_out,
-                    p->d_cf0, p->d_fsize, p->d_fsamp, p->d_cfn, p->d_crc};
+                    p->d_cf0, p->d_fsize, p->d_fsamp, p->d_cfn, p->d_crc, p->d_part};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -878,6 +878,7 @@ LosslessPlan *lossless_plan_create(const std::vector<uint64_t> &n_il, const std:
         LCHK(hipMalloc(&p->d_fsamp, fsamp.size() * 4));
         LCHK(hipMalloc(&p->d_fsize, (nf + 1) * 4));
         LCHK(hipMalloc(&p->d_crc, (p->n_clips + 1) * 4));
+        LCHK(hipMalloc(&p->d_part, (p->n_clips * finish_parts_for(p->n_clips) + 1) * 4));
         LCHK(hipMemcpy(p->d_cf0, cf0.data(), cf0.size() * 8, hipMemcpyHostToDevice));
         LCHK(hipMemcpy(p->d_cfn, cfn.data(), cfn.size() * 4, hipMemcpyHostToDevice));
         LCHK(hipMemcpy(p->d_fsamp, fsamp.data(), fsamp.size() * 4, hipMemcpyHostToDevice));
@@ -942,6 +943,8 @@ int lossless_encode_launch(LosslessPlan *p, hipStream_t s, int profile, std::str
     F.level = p->level;
     F.n_clips = (int)p->n_clips;
     F.crc_out = p->d_crc;
+    F.parts = finish_parts_for(p->n_clips);
+    F.part_reg = p->d_part;
     if (launch_finish_files(F, s) != 0) {
         err = "finish_files launch failed";
         return -1;

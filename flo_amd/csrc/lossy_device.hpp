@@ -646,6 +646,24 @@ __device__ __forceinline__ void quantise(const int lane, const float (&c)[CH][16
 }
 
 // ------------------------------------------------------------------------------------------------ sparse RLE
+// Non-zero mask of the lane's 16 values (bit e = value e). An add-with-carry chain (compare sets the carry, v_addc
+// shifts it in: two instructions per value instead of three) was tried and lost: sixteen dependent steps.
+__device__ __forceinline__ uint32_t nonzero_mask16(const int (&q)[16]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++) m |= (q[e] != 0 ? 1u : 0u) << e;
+    return m;
+}
+// The same for 16 values held as i16 pairs in 8 dwords (value 2k in the low half of x[k]); hi[k] = x[k] >> 16.
+__device__ __forceinline__ uint32_t nonzero_mask16_packed(const uint32_t (&x)[8], const uint32_t (&hi)[8]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        m |= ((x[k] & 0xFFFFu) != 0u ? 1u : 0u) << (2 * k);
+        m |= (hi[k] != 0u ? 1u : 0u) << (2 * k + 1);
+    }
+    return m;
+}
 // inclusive prefix sum over the wave: Hillis-Steele inside each row of 16 lanes, then two row broadcasts
 __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
     int v = (int)x;
@@ -674,10 +692,8 @@ struct SparsePlan {
     uint32_t total;    // total sparse bytes (uniform)
 };
 
-__device__ __forceinline__ void sparse_plan(const int lane, const int (&q)[16], SparsePlan &P) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int e = 0; e < 16; e++) m |= (q[e] != 0 ? 1u : 0u) << e;
+// m = non-zero mask of the lane's 16 values (bit e = value e)
+__device__ __forceinline__ void sparse_plan_m(const int lane, const uint32_t m, SparsePlan &P) {
     const uint32_t prev_m = (uint32_t)dpp_i<0x138>(0, (int)m);  // mask of lane - 1 (0 for lane 0)
     const uint32_t prev_nz = (prev_m >> 15) & 1u;
     uint32_t zs = ~m & ((m << 1) | prev_nz) & 0xFFFFu;
@@ -727,6 +743,9 @@ __device__ __forceinline__ void sparse_plan(const int lane, const int (&q)[16], 
     const uint32_t incl = wave_incl_sum(bytes);
     P.off0 = incl - bytes;
     P.total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+}
+__device__ __forceinline__ void sparse_plan(const int lane, const int (&q)[16], SparsePlan &P) {
+    sparse_plan_m(lane, nonzero_mask16(q), P);
 }
 
 // Emit this lane's part of the sparse blobs of CH channels (LDS bytes; blob c starts at dst[c][0]). Zero values and

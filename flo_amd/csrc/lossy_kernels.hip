@@ -474,24 +474,29 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
             const int ln = lane_id_opaque();
             wait_counter(&cs.ready[0], h + 1);
             wait_counter(&cs.ready[1], h + 1);
+            // the values stay packed: element 2k is the low half of a dword (the stores below only look at its low 16
+            // bits), element 2k + 1 its high half; the non-zero masks come straight from the packed words
             int q[2][16];
-            uint32_t sfw[2];
+            uint32_t sfw[2], msk[2];
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(cs.qh[ch]);
                 const uint4 x0 = src[ln], x1 = src[64 + ln];
                 const uint32_t xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                uint32_t hi[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    q[ch][2 * k] = (int)(short)(xs[k] & 0xFFFFu);
-                    q[ch][2 * k + 1] = (int)xs[k] >> 16;
+                    hi[k] = xs[k] >> 16;
+                    q[ch][2 * k] = (int)xs[k];
+                    q[ch][2 * k + 1] = (int)hi[k];
                 }
+                msk[ch] = nonzero_mask16_packed(xs, hi);
                 sfw[ch] = cs.sfwh[ch][ln & 31];
             }
             set_counter(&cs.consumed, h + 1);
             SparsePlan P[2];
-            sparse_plan(ln, q[0], P[0]);
-            sparse_plan(ln, q[1], P[1]);
+            sparse_plan_m(ln, msk[0], P[0]);
+            sparse_plan_m(ln, msk[1], P[1]);
             uint32_t tot[2] = {P[0].total, P[1].total};
             // the < 16 bytes the previous frame left unflushed go back to the front of the staging buffer
             if (ln < (int)pend) stage[ln] = (uint8_t)tailb;
