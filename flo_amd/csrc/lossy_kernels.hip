@@ -660,12 +660,24 @@ __global__ void lossy_scan_kernel(LossyArgs A) {
     const unsigned long long f0 = A.clip_frame0[clip];
     const unsigned fw = fs >= kScanBlock ? fs - kScanBlock : 0;
     const unsigned fe = fs + kScanBlock < hops ? fs + kScanBlock : hops;
+    // The recurrence is a serial chain, the loads are not: fetch sixteen levels at a time, then run the chain on
+    // registers (one thread would otherwise pay a full memory latency per frame, 128 times in a row).
     float s = 0.f;
-    for (unsigned h = fw; h < fs; h++) s = fmaxf(A.a_t[((f0 + h) * A.nch + ch) * 32 + band], s * 0.7f);
-    for (unsigned h = fs; h < fe; h++) {
-        const unsigned long long idx = ((f0 + h) * A.nch + ch) * 32 + band;
-        A.s_prev_out[idx] = s;
-        s = fmaxf(A.a_t[idx], s * 0.7f);
+    const unsigned long long stride = (unsigned long long)A.nch * 32;
+    const float *at = A.a_t + (f0 * A.nch + ch) * 32 + band;
+    float *sp = A.s_prev_out + (f0 * A.nch + ch) * 32 + band;
+    for (unsigned h0 = fw; h0 < fe; h0 += 16) {
+        float a[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) a[j] = h0 + j < fe ? at[(unsigned long long)(h0 + j) * stride] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const unsigned h = h0 + j;
+            if (h < fe) {
+                if (h >= fs) sp[(unsigned long long)h * stride] = s;
+                s = fmaxf(a[j], s * 0.7f);
+            }
+        }
     }
 }
 
@@ -686,30 +698,33 @@ __global__ void lossy_compact_kernel(LossyArgs A) {
     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
 }
 
-// exclusive scan of frame sizes inside each clip: one workgroup per clip, 256 frames per pass with a running carry
+// exclusive scan of frame sizes inside each clip: one workgroup per clip
 __global__ __launch_bounds__(256) void lossy_frame_offsets_kernel(LossyArgs A) {
     __shared__ unsigned long long sc[256];
     const unsigned clip = blockIdx.x;
     if (clip >= (unsigned)A.n_clips) return;
     const unsigned long long f0 = A.clip_frame0[clip];
     const unsigned hops = A.clip_hops[clip];
-    unsigned long long carry = 0;
-    for (unsigned base = 0; base < hops; base += 256) {
-        const unsigned h = base + threadIdx.x;
-        const unsigned long long v = h < hops ? A.frame_size[f0 + h] : 0;
-        sc[threadIdx.x] = v;
+    // thread t owns a contiguous run of frames: run sums, one block scan, then the offsets of the run
+    const unsigned t = threadIdx.x;
+    const unsigned per = (hops + 255) / 256;
+    const unsigned h0 = t * per < hops ? t * per : hops, h1 = h0 + per < hops ? h0 + per : hops;
+    unsigned long long sum = 0;
+    for (unsigned h = h0; h < h1; h++) sum += A.frame_size[f0 + h];
+    sc[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        unsigned long long v = t >= (unsigned)d ? sc[t - d] : 0;
         __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {
-            unsigned long long t = threadIdx.x >= (unsigned)d ? sc[threadIdx.x - d] : 0;
-            __syncthreads();
-            sc[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (h < hops) A.frame_off[f0 + h] = carry + sc[threadIdx.x] - v;
-        carry += sc[255];
+        sc[t] += v;
         __syncthreads();
     }
-    if (threadIdx.x == 0) A.clip_bytes[clip] = carry;
+    unsigned long long off = sc[t] - sum;
+    for (unsigned h = h0; h < h1; h++) {
+        A.frame_off[f0 + h] = off;
+        off += A.frame_size[f0 + h];
+    }
+    if (t == 255) A.clip_bytes[clip] = sc[255];
 }
 
 // ---------------------------------------------------------------------------------------------- stage kernels
