@@ -318,7 +318,16 @@ extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size
     for (size_t i = 0; i < n_clips; i++) {
         b->clip_off[i] = off;
         b->clip_nsf[i] = n_interleaved[i] / ch;  // trailing partial sample-frame is dropped (encoder.rs:174)
-        off += (n_interleaved[i] + 3) & ~(uint64_t)3;
+        uint64_t alloc = n_interleaved[i];
+        if (mode == FLO_MODE_LOSSY) {
+            // every frame's 1024 new sample-frames exist in memory: the clip is followed by zeros up to
+            // hops * 1024 sample-frames (the reference pads the same way, encoder.rs:177-185), so the chain kernels
+            // load whole half-frames without bounds checks
+            const uint64_t hops = (b->clip_nsf[i] + 1024 + 1023) / 1024;
+            alloc = hops * 1024 * ch;
+            if (alloc < n_interleaved[i]) alloc = n_interleaved[i];
+        }
+        off += (alloc + 3) & ~(uint64_t)3;
     }
     b->total_floats = off;
     int rc = FLO_OK;
@@ -336,6 +345,7 @@ extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size
         }                                                                                           \
     } while (0)
     BCHK(hipMalloc(&b->d_pcm, (b->total_floats + 4) * sizeof(float)));
+    if (mode == FLO_MODE_LOSSY) BCHK(hipMemset(b->d_pcm, 0, (b->total_floats + 4) * sizeof(float)));   // the padding
     if (mode == FLO_MODE_LOSSY) {
         rc = get_tables(c, sr, qol, &b->ts);
         if (rc != FLO_OK) return bail(rc);
@@ -403,9 +413,10 @@ extern "C" int flo_batch_upload(flo_batch *b, size_t clip, const float *pcm) {
     if (!b || clip >= b->n_clips || (!pcm && b->n_il[clip])) return FLO_ERR_ARG;
     flo_ctx *c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
-    if (b->n_il[clip])
-        HIPCHK(c, hipMemcpyAsync(b->d_pcm + b->clip_off[clip], pcm, b->n_il[clip] * sizeof(float),
-                                 hipMemcpyHostToDevice, c->stream));
+    // a trailing partial sample-frame is not part of the clip (encoder.rs:174): it must not land in the zero padding
+    const uint64_t n_copy = b->mode == FLO_MODE_LOSSY ? b->clip_nsf[clip] * b->ch : b->n_il[clip];
+    if (n_copy)
+        HIPCHK(c, hipMemcpyAsync(b->d_pcm + b->clip_off[clip], pcm, n_copy * sizeof(float), hipMemcpyHostToDevice, c->stream));
     b->encoded = b->synced = false;
     return FLO_OK;
 }
@@ -479,6 +490,12 @@ extern "C" int flo_batch_encode(flo_batch *b, int which) {
         return rc == 0 ? FLO_OK : fail(c, FLO_ERR_DEVICE, "lossless encode: " + err);
     }
     if (!b->total_frames) return FLO_OK;
+    // a caller who wrote all n_interleaved floats through flo_batch_clip_device_ptr left a partial sample-frame in the
+    // zero padding behind the clip: it is not part of the clip (encoder.rs:174)
+    for (size_t i = 0; i < b->n_clips; i++) {
+        const uint64_t part = b->n_il[i] % b->ch;
+        if (part) HIPCHK(c, hipMemsetAsync(b->d_pcm + b->clip_off[i] + b->clip_nsf[i] * b->ch, 0, part * sizeof(float), c->stream));
+    }
     if (which == 0) which = c->force_path;
     if (which == 0) which = (b->n_clips * b->ch >= 512) ? (b->ch == 2 ? 3 : 1) : 2;
     int rc;

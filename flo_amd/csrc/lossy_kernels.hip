@@ -267,7 +267,6 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
     T.pack = reinterpret_cast<const float4 *>(lds_raw);
 
     const float *pcm = A.pcm + A.clip_off[clip];
-    const long long n_sf = (long long)A.clip_nsf[clip];
     const unsigned hops = A.clip_hops[clip];
     const unsigned long long frame0 = A.clip_frame0[clip];
     uint8_t *gout = A.out + A.out_off[clip];
@@ -279,8 +278,7 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
 #pragma unroll
     for (int r = 0; r < 8; r++) ae[0][r] = ao[0][r] = 0.f;  // pre-roll: 1024 zeros (encoder.rs:177)
     if (!A.in_coeffs) {
-        if (n_sf >= 1024) load_half_fast<1>(lane, pcm, NW, w, 0, be, bo);
-        else load_half<1>(lane, pcm, n_sf, NW, w, 0, be, bo);
+        load_half_fast<1>(lane, pcm, NW, w, 0, be, bo);   // the batch pads every clip with zeros to hops * 1024 sample-frames
     }
     unsigned long long written = 0;
     uint32_t pend = 0, step = 0, tailb = 0;
@@ -308,8 +306,7 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
             // consumed at the top of the next call, where the two register sets have swapped roles
             if (h + 1 < hops) {
                 const long long s0 = (long long)(h + 1) * 1024;
-                if (s0 + 1024 <= n_sf) load_half_fast<1>(ln, pcm, NW, w, s0, pe, po);
-                else load_half<1>(ln, pcm, n_sf, NW, w, s0, pe, po);
+                load_half_fast<1>(ln, pcm, NW, w, s0, pe, po);
             }
 #if FLO_ABLATE >= 6
             for (int r = 0; r < 8; r++) { FLO_KEEP(zr[0][r]); FLO_KEEP(zi[0][r]); }
@@ -524,7 +521,6 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
     LossyDevTables T = A.T;
     T.pack = reinterpret_cast<const float4 *>(lds_raw);
     const float *pcm = A.pcm + A.clip_off[clip];
-    const long long n_sf = (long long)A.clip_nsf[clip];
 
     FrameState<1> st;
     st.prev[0] = 0.f;
@@ -532,8 +528,7 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
 #pragma unroll
     for (int r = 0; r < 8; r++) ae[0][r] = ao[0][r] = 0.f;  // pre-roll: 1024 zeros (encoder.rs:177)
     if (!A.in_coeffs) {
-        if (n_sf >= 1024) load_half_fast<1>(lane, pcm, 2, w, 0, be, bo);
-        else load_half<1>(lane, pcm, n_sf, 2, w, 0, be, bo);
+        load_half_fast<1>(lane, pcm, 2, w, 0, be, bo);   // the batch pads every clip with zeros to hops * 1024 sample-frames
     }
     auto frame_body = [&](const unsigned h, float (&pe)[1][8], float (&po)[1][8], float (&ce)[1][8],
                           float (&co)[1][8]) __attribute__((always_inline)) {
@@ -551,8 +546,7 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
             fold<1>(ln, pe, po, ce, co, zr, zi, T);
             if (h + 1 < hops) {
                 const long long s0 = (long long)(h + 1) * 1024;
-                if (s0 + 1024 <= n_sf) load_half_fast<1>(ln, pcm, 2, w, s0, pe, po);
-                else load_half<1>(ln, pcm, n_sf, 2, w, s0, pe, po);
+                load_half_fast<1>(ln, pcm, 2, w, s0, pe, po);
             }
             fft512<1>(ln, zr, zi, lds.u.xch, T);
             post_rotate_transpose<1>(ln, zr, zi, lds.u.coef, c, T);
