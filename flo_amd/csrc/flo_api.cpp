@@ -322,9 +322,10 @@ extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size
         if (mode == FLO_MODE_LOSSY) {
             // every frame's 1024 new sample-frames exist in memory: the clip is followed by zeros up to
             // hops * 1024 sample-frames (the reference pads the same way, encoder.rs:177-185), so the chain kernels
-            // load whole half-frames without bounds checks
+            // load whole half-frames without bounds checks; one more half-frame lets them prefetch unconditionally
+            // behind the last frame (the values are never used)
             const uint64_t hops = (b->clip_nsf[i] + 1024 + 1023) / 1024;
-            alloc = hops * 1024 * ch;
+            alloc = (hops + 1) * 1024 * ch;
             if (alloc < n_interleaved[i]) alloc = n_interleaved[i];
         }
         off += (alloc + 3) & ~(uint64_t)3;

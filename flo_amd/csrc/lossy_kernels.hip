@@ -304,10 +304,9 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
             STAMP(0);
             // the older half is dead after the fold: the half-frame after next is loaded into its registers now and
             // consumed at the top of the next call, where the two register sets have swapped roles
-            if (h + 1 < hops) {
-                const long long s0 = (long long)(h + 1) * 1024;
-                load_half_fast<1>(ln, pcm, NW, w, s0, pe, po);
-            }
+            // unconditional, also behind the last frame (the batch allocates one spare half-frame per clip): a
+            // conditional load would merge "loaded" and "kept" registers and cost 16 copies per frame
+            load_half_fast<1>(ln, pcm, NW, w, (long long)(h + 1) * 1024, pe, po);
 #if FLO_ABLATE >= 6
             for (int r = 0; r < 8; r++) { FLO_KEEP(zr[0][r]); FLO_KEEP(zi[0][r]); }
             return;
@@ -544,10 +543,7 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
         } else {
             float zr[1][8], zi[1][8];
             fold<1>(ln, pe, po, ce, co, zr, zi, T);
-            if (h + 1 < hops) {
-                const long long s0 = (long long)(h + 1) * 1024;
-                load_half_fast<1>(ln, pcm, 2, w, s0, pe, po);
-            }
+            load_half_fast<1>(ln, pcm, 2, w, (long long)(h + 1) * 1024, pe, po);   // unconditional: see lossy_chain_kernel
             fft512<1>(ln, zr, zi, lds.u.xch, T);
             post_rotate_transpose<1>(ln, zr, zi, lds.u.coef, c, T);
             store_coeffs_dbg<1>(ln, c, A, frame0 + h, w);
