@@ -119,12 +119,16 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if gather is not None:
+        gather.flush()
     ctx.profile_reset()
     ctx.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if gather is not None:
+        gather.flush()     # the last transfers (the gather of step k overlaps the encode of step k + 1)
     barrier()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from flo_amd.dist import contiguous_shard, gather_payloads, shard_clips
+from flo_amd.dist import PipelinedGather, contiguous_shard, gather_payloads, shard_clips
 
 
 def test_shard_clips_partition_and_balance():
@@ -75,6 +75,59 @@ def test_variable_size_gather_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _payload(rank, step):
+    rng = np.random.default_rng(1000 * rank + step)
+    n = [3000, 0, 70000, 17, 4096, 1][step % 6] + 11 * rank
+    return torch.from_numpy(rng.integers(0, 256, n, dtype=np.uint8))
+
+
+def _pipe_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pipe = PipelinedGather(dist, rank, world, 0, 2)
+        steps = 7
+        seen = []
+        for k in range(steps):
+            slot = k % 2
+            out = pipe.retire(slot)          # the transfer of step k - 2
+            if out is not None and rank == 0:
+                seen.append((k - 2, [t.clone() for t in out]))
+            pipe.submit(slot, _payload(rank, k))
+        # the two transfers still in flight, oldest first
+        first = steps % 2
+        for j, slot in enumerate((first, 1 - first)):
+            out = pipe.retire(slot)
+            if rank == 0:
+                seen.append((steps - 2 + j, [t.clone() for t in out]))
+        assert pipe.flush() == [None, None]
+        if rank == 0:
+            assert [k for k, _ in seen] == list(range(steps))
+            for k, out in seen:
+                for r in range(world):
+                    assert out[r].numpy().tobytes() == _payload(r, k).numpy().tobytes(), (k, r)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]

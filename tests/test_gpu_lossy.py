@@ -282,6 +282,18 @@ def test_pack_streams_and_single_rank_rccl_gather(ctx):
     try:
         got, sizes = gather_payloads(dist, buf[: offs[-1]], 0, 1, 0)
         assert sizes == [offs[-1]] and got[0].data_ptr() == buf.data_ptr()
+        # the per-step object bench.py uses for N > 1: packs finished files, double-buffered, pipelined
+        from flo_amd.dist import BitstreamGather
+        g = BitstreamGather(ctx, b, dist, 0, 1, 0)
+        for _ in range(3):
+            b.encode(0)
+            b.sync()
+            foffs2 = g.run()
+            assert foffs2 == foffs
+        outs = g.flush()
+        assert g.last_total == foffs[-1]
+        newest = [o for o in outs if o is not None][-1][0].cpu().numpy()
+        assert newest[foffs[1]:foffs[1] + len(b.fetch(1))].tobytes() == b.fetch(1)
     finally:
         dist.destroy_process_group()
     b.close()
