@@ -301,8 +301,8 @@ extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size
     *out = nullptr;
     if (ch == 0 || sr == 0) return fail(c, FLO_ERR_ARG, "sample_rate and channels must be non-zero");
     if (mode != FLO_MODE_LOSSY && mode != FLO_MODE_LOSSLESS) return fail(c, FLO_ERR_ARG, "unknown mode");
-    if (mode == FLO_MODE_LOSSY && ch > 2)
-        return fail(c, FLO_ERR_ARG, "lossy encode on device supports 1 or 2 channels in this build");
+    if (mode == FLO_MODE_LOSSY && ch > kMaxLossyChannels)
+        return fail(c, FLO_ERR_ARG, "lossy encode on device supports 1 to 8 channels");
     HIPCHK(c, hipSetDevice(c->device));
     flo_batch *b = new flo_batch();
     b->ctx = c;
@@ -468,6 +468,7 @@ static LossyArgs make_args(flo_batch *b) {
     A.s_prev_out = b->d_sprev;
     A.s_prev = b->d_sprev;
     A.slots = b->d_slots;
+    A.slot_bytes = lossy_slot_bytes(b->ch);
     A.frame_off = (unsigned long long *)b->d_frame_off;
     A.dbg_coeffs = b->d_dbg_coeffs;
     A.dbg_q = b->d_dbg_q;
@@ -499,6 +500,7 @@ extern "C" int flo_batch_encode(flo_batch *b, int which) {
     }
     if (which == 0) which = c->force_path;
     if (which == 0) which = (b->n_clips * b->ch >= 512) ? (b->ch == 2 ? 3 : 1) : 2;
+    if (b->ch > 2) which = 2;   // more than two channels: the generic frame-parallel kernels
     int rc;
     if (which == 1 || (which == 3 && b->ch != 2)) {
 #ifdef FLO_STAMPS
@@ -514,7 +516,7 @@ extern "C" int flo_batch_encode(flo_batch *b, int which) {
             size_t n = (size_t)b->total_frames * b->ch * 32 * sizeof(float);
             HIPCHK(c, hipMalloc(&b->d_at, n));
             HIPCHK(c, hipMalloc(&b->d_sprev, n));
-            HIPCHK(c, hipMalloc(&b->d_slots, (size_t)b->total_frames * kFrameCap));
+            HIPCHK(c, hipMalloc(&b->d_slots, (size_t)b->total_frames * lossy_slot_bytes(b->ch)));
             HIPCHK(c, hipMalloc(&b->d_frame_off, (size_t)(b->total_frames + 1) * 8));
         }
         LossyArgs A = make_args(b);

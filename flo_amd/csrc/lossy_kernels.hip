@@ -124,9 +124,9 @@ __device__ __forceinline__ uint32_t emit_frame(const int lane, uint8_t *f, int n
                                                const uint32_t (&sfw)[CH], const SparsePlan (&P)[CH],
                                                const int (&q)[CH][16]) {
     uint32_t pos = 12 + 50 * (uint32_t)nch;
-    uint32_t chpos[2];
+    uint32_t chpos[CH];   // positions of this call's channels ch0 .. ch0 + CH - 1
     for (int c = 0; c < nch; c++) {
-        chpos[c] = pos;
+        if (c >= ch0 && c < ch0 + CH) chpos[c - ch0] = pos;
         pos += 4 + tot[c];
     }
     const uint32_t flen = pos, blob_len = flen - 10;
@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t emit_frame(const int lane, uint8_t *f, int n
         }
         if (lane == 32) {
             const uint32_t l = tot[c];
-            uint8_t *p = f + chpos[c];
+            uint8_t *p = f + chpos[ch];
             p[0] = (uint8_t)l; p[1] = (uint8_t)(l >> 8); p[2] = (uint8_t)(l >> 16); p[3] = (uint8_t)(l >> 24);
         }
     }
@@ -157,9 +157,8 @@ __device__ __forceinline__ uint32_t emit_frame(const int lane, uint8_t *f, int n
     uint32_t trash[CH];
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
-        const int c = ch0 + ch;
-        dsts[ch] = f + chpos[c] + 4;
-        trash[ch] = (flen - (chpos[c] + 4)) + 2u * (uint32_t)lane + 128u * (uint32_t)ch;
+        dsts[ch] = f + chpos[ch] + 4;
+        trash[ch] = (flen - (chpos[ch] + 4)) + 2u * (uint32_t)lane + 128u * (uint32_t)ch;
     }
     sparse_emit_n<CH>(lane, q, P, dsts, trash);
     return flen;
@@ -627,7 +626,83 @@ __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
     if (lane == 0) A.frame_size[gframe] = flen;
     const uint32_t n16 = (flen + 15) >> 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(stage);
-    uint4 *dst = reinterpret_cast<uint4 *>(A.slots + gframe * (unsigned long long)kFrameCap);
+    uint4 *dst = reinterpret_cast<uint4 *>(A.slots + gframe * (unsigned long long)A.slot_bytes);
+    for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
+}
+
+// Any channel count up to kMaxLossyChannels: one wave per frame walks the channels one after the other with the
+// single-channel device functions. Pass 2 parks every channel's integers (i16) in LDS because the byte position of a
+// channel's sparse blob depends on the sizes of the channels before it, then plans again and emits in channel order.
+template <int PASS, bool EXACT>
+__global__ __launch_bounds__(64) void lossy_frame_n_kernel(LossyArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn[];   // stage[slot_bytes + 256] | park[nch][1024] i16
+    __shared__ WaveLds<1> lds;
+    __shared__ uint32_t s_tot[kMaxLossyChannels], s_sfw[kMaxLossyChannels][32];
+    const int lane = lane_id();
+    const unsigned long long gframe = blockIdx.x;
+    if (gframe >= A.total_frames) return;
+    int lo = 0, hi = A.n_clips - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (A.clip_frame0[mid] <= gframe) lo = mid; else hi = mid - 1;
+    }
+    const unsigned clip = (unsigned)lo;
+    const unsigned h = (unsigned)(gframe - A.clip_frame0[clip]);
+    const float *pcm = A.pcm + A.clip_off[clip];
+    const long long n_sf = (long long)A.clip_nsf[clip];
+    const int nch = A.nch;
+    uint8_t *stage = dyn;
+    short *park = reinterpret_cast<short *>(dyn + A.slot_bytes + 256);
+
+    LaneConst L;
+    load_lane_const(lane, L, A.T);
+    if (lane == 0) lds.slots[0][kZeroSlot] = make_float2(0.f, 0.f);
+    for (int ch = 0; ch < nch; ch++) {
+        float c[1][16];
+        if (A.in_coeffs) {
+            load_coeffs<1>(lane, c, A, gframe, ch);
+        } else {
+            float ae[1][8], ao[1][8], be[1][8], bo[1][8];
+            load_half<1>(lane, pcm, n_sf, nch, ch, (long long)h * 1024 - 1024, ae, ao);
+            load_half<1>(lane, pcm, n_sf, nch, ch, (long long)h * 1024, be, bo);
+            mdct_frame<1>(lane, ae, ao, be, bo, lds, A.T, c);
+        }
+        FrameState<1> st;
+        int q[1][16];
+        uint32_t sfw[1];
+        SparsePlan P[1];
+        if (PASS == 1) {
+            st.prev[0] = 0.f;
+            analyse_frame<1, true, EXACT>(lane, c, lds, L, A, A.T, ch, st, gframe, q, sfw, P);
+            continue;
+        }
+        store_coeffs_dbg<1>(lane, c, A, gframe, ch);
+        st.prev[0] = lane < 25 ? A.s_prev[(gframe * nch + ch) * 32 + lane] : 0.f;
+        analyse_frame<1, false, EXACT>(lane, c, lds, L, A, A.T, ch, st, gframe, q, sfw, P);
+#pragma unroll
+        for (int e = 0; e < 16; e++) park[ch * 1024 + 16 * lane + e] = (short)q[0][e];
+        if (lane < 32) s_sfw[ch][lane] = sfw[0];
+        if (lane == 0) s_tot[ch] = P[0].total;
+        wave_sync();
+    }
+    if (PASS == 1) return;
+    uint32_t tot[kMaxLossyChannels];
+    for (int ch = 0; ch < kMaxLossyChannels; ch++) tot[ch] = ch < nch ? s_tot[ch] : 0u;
+    uint32_t flen = 0;
+    for (int ch = 0; ch < nch; ch++) {
+        int q[1][16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) q[0][e] = park[ch * 1024 + 16 * lane + e];
+        uint32_t sfw[1] = {s_sfw[ch][lane & 31]};
+        SparsePlan P[1];
+        sparse_plan(lane, q[0], P[0]);
+        flen = emit_frame<1>(lane, stage, nch, ch, tot, sfw, P, q);
+        wave_sync();
+    }
+    if (lane == 0) A.frame_size[gframe] = flen;
+    const uint32_t n16 = (flen + 15) >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(stage);
+    uint4 *dst = reinterpret_cast<uint4 *>(A.slots + gframe * (unsigned long long)A.slot_bytes);
     for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
 }
 
@@ -683,7 +758,7 @@ __global__ void lossy_compact_kernel(LossyArgs A) {
     const unsigned clip = (unsigned)lo;
     const unsigned long long off = A.frame_off[gframe];  // byte offset inside the clip's DATA chunk
     const uint32_t len = A.frame_size[gframe];
-    const uint8_t *src = A.slots + gframe * (unsigned long long)kFrameCap;
+    const uint8_t *src = A.slots + gframe * (unsigned long long)A.slot_bytes;
     uint8_t *dst = A.out + A.out_off[clip] + off;
     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
 }
@@ -860,6 +935,11 @@ int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s) {
         if (pass == 1) hipLaunchKernelGGL((lossy_frame_kernel<2, 1, false>), g, b, 0, s, A);
         else if (A.exact) hipLaunchKernelGGL((lossy_frame_kernel<2, 2, true>), g, b, 0, s, A);
         else hipLaunchKernelGGL((lossy_frame_kernel<2, 2, false>), g, b, 0, s, A);
+    } else if (A.nch <= kMaxLossyChannels) {
+        const size_t dynb = (size_t)A.slot_bytes + 256 + (size_t)A.nch * 2048;
+        if (pass == 1) hipLaunchKernelGGL((lossy_frame_n_kernel<1, false>), g, b, dynb, s, A);
+        else if (A.exact) hipLaunchKernelGGL((lossy_frame_n_kernel<2, true>), g, b, dynb, s, A);
+        else hipLaunchKernelGGL((lossy_frame_n_kernel<2, false>), g, b, dynb, s, A);
     } else return -1;
     FLO_LAUNCH_CHECK();
     return 0;

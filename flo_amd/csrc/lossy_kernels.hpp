@@ -28,7 +28,8 @@ struct LossyArgs {
     float *a_t;                              // [total_frames][nch][32] masking level before temporal masking
     float *s_prev_out;                       // [total_frames][nch][32] scan output
     const float *s_prev;                     // same buffer, read by pass 2
-    uint8_t *slots;                          // [total_frames][kFrameCap]
+    uint8_t *slots;                          // [total_frames][slot_bytes]
+    unsigned int slot_bytes;                 // kFrameCap for 1-2 channels, lossy_slot_bytes(nch) beyond
     unsigned long long *frame_off;           // [total_frames] offset of the frame inside its clip's DATA chunk
     // analysis / stage tests (may be null)
     float *dbg_coeffs;                       // [total_frames][nch][1024]
@@ -42,6 +43,13 @@ struct LossyArgs {
 int launch_lossy_chain(const LossyArgs &A, hipStream_t s);
 int launch_lossy_chain3(const LossyArgs &A, hipStream_t s);   // stereo only: two channel waves + one packer wave per clip
 int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s);
+// bytes reserved per frame in the frame-parallel form: header + scale words + every channel's largest sparse blob
+inline unsigned int lossy_slot_bytes(int nch) {
+    unsigned int need = 12u + 50u * (unsigned)nch + (unsigned)nch * (4u + 2064u) + 16u;
+    need = (need + 15u) & ~15u;
+    return need < (unsigned)kFrameCap ? (unsigned)kFrameCap : need;
+}
+constexpr int kMaxLossyChannels = 8;      // more channels than two take the generic frame-parallel kernel
 int launch_lossy_scan(const LossyArgs &A, hipStream_t s);
 int launch_lossy_compact(const LossyArgs &A, hipStream_t s);
 int launch_mdct_only(const LossyDevTables &T, const float *frames, unsigned long long n, float *out, hipStream_t s);

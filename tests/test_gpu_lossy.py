@@ -313,3 +313,20 @@ def test_blocked_scan_matches_sequential_chain_on_long_decays(ctx):
     b = ctx.encode_lossy(x, sr, 2, 0.55)
     ctx.force_path(0)
     assert a == b and len(flofile.parse(a).frames) == (n + 1024 + 1023) // 1024
+
+
+@pytest.mark.parametrize("ch", [3, 6, 8])
+def test_more_than_two_channels(ctx, ch):
+    # beyond stereo the generic frame-parallel kernels walk the channels of a frame one after the other
+    sr, n = 44100, 30000
+    pcm = signals.music_like(sr, n, ch, seed=70 + ch)
+    for q in (0.35, 1.0):
+        compare_lossy_stage(ctx.lossy_analyze(pcm, sr, ch, q), O.lossy_analyze(pcm, sr, ch, q), sr, f"ch{ch} q{q}")
+        g = ctx.encode_lossy(pcm, sr, ch, q)
+        o = O.encode_lossy(pcm, sr, ch, q)
+        fg, fo = same_structure(g, o)
+        assert fg.channels == ch and len(fg.frames) == (n + 1024 + 1023) // 1024
+        dg, do = ctx.decode(g), O.decode(g)[0]
+        assert dg.shape == do.shape and np.max(np.abs(dg - do)) <= 2e-6
+    with pytest.raises(Exception):
+        ctx.encode_lossy(signals.music_like(sr, 2000, 9, seed=1), sr, 9, 0.55)
