@@ -342,7 +342,7 @@ __device__ __forceinline__ void load_half_fast(const int lane, const float *__re
 }
 
 // Fold first half (ae, ao) and second half (be, bo) into the 8 complex FFT inputs of this lane
-// (window, butterflies and pre-rotation of mdct.rs:174-197, same operation order per element).
+// (window, butterflies and pre-rotation of mdct.rs:174-197).
 template <int CH>
 __device__ __forceinline__ void fold(const int lane, const float (&ae)[CH][8], const float (&ao)[CH][8], const float (&be)[CH][8],
                                      const float (&bo)[CH][8], float (&zr)[CH][8], float (&zi)[CH][8],
@@ -355,18 +355,20 @@ __device__ __forceinline__ void fold(const int lane, const float (&ae)[CH][8], c
         const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
 #pragma unroll
         for (int c = 0; c < CH; c++) {
+            // One product and one fused multiply-add per value (the reference rounds both products; like the FFT's
+            // own arithmetic this differs from it at the 1e-7 level, far inside the transform's parity tolerance).
             float re, im;
             if (r < 4) {
                 // re = -x[2i+n3] - x[n3-1-2i];  im = -x[n4+2i] + x[n4-1-2i]
-                re = -(be[c][r] * wbe) - (bo[c][r] * wbo);
-                im = -(ae[c][r] * wae) + (ao[c][r] * wao);
+                re = fmaf(-bo[c][r], wbo, -(be[c][r] * wbe));
+                im = fmaf(ao[c][r], wao, -(ae[c][r] * wae));
             } else {
                 // re2 = x[2i] - x[n2-1-2i];  im2 = -x[n2+2i] - x[n-1-2i]
-                re = (ae[c][r] * wae) - (ao[c][r] * wao);
-                im = -(be[c][r] * wbe) - (bo[c][r] * wbo);
+                re = fmaf(-ao[c][r], wao, ae[c][r] * wae);
+                im = fmaf(-bo[c][r], wbo, -(be[c][r] * wbe));
             }
-            zr[c][r] = -re * w.x - im * w.y;
-            zi[c][r] = re * w.y - im * w.x;
+            zr[c][r] = fmaf(-im, w.y, -(re * w.x));
+            zi[c][r] = fmaf(re, w.y, -(im * w.x));
         }
     }
 }
@@ -386,8 +388,8 @@ __device__ __forceinline__ void post_rotate_transpose(const int lane, const floa
         const int p0 = k0 + 4 * (k0 >> 4), p1 = k1 + 4 * (k1 >> 4);
 #pragma unroll
         for (int ch = 0; ch < CH; ch++) {
-            float R = -zr[ch][r] * w.x - zi[ch][r] * w.y;
-            float I = -zr[ch][r] * w.y + zi[ch][r] * w.x;
+            float R = fmaf(-zi[ch][r], w.y, -(zr[ch][r] * w.x));
+            float I = fmaf(zi[ch][r], w.x, -(zr[ch][r] * w.y));
             coef[ch][p0] = R;
             coef[ch][p1] = I;
         }
