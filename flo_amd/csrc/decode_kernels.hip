@@ -157,30 +157,77 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
 }
 
 // ------------------------------------------------------------------------------------------------ ALPC frames
-struct BitRd {   // rice.rs:217-259
+// MSB-first bit reader with the semantics of rice.rs:217-259 (a bit past the end reads as 0 and does not advance;
+// "exhausted" = every real bit consumed), buffered: up to 64 bits sit in a register, refilled a byte at a time, so the
+// unary part of a Rice code is one count-leading-ones instead of a loop over bits. (A deeper variant that prefetched
+// aligned 8-byte words one ahead was measured and was no faster: the per-sample control flow, not the loads, is
+// what a single serial lane spends its time on.)
+struct BitRd {
     const uint8_t *p;
-    uint32_t len, byte_pos, bit_pos;
-    __device__ __forceinline__ bool exhausted() const { return byte_pos >= len; }
-    __device__ __forceinline__ uint32_t bit() {
-        if (byte_pos >= len) return 0;
-        const uint32_t b = (p[byte_pos] >> (7 - bit_pos)) & 1u;
-        if (++bit_pos == 8) {
-            bit_pos = 0;
-            byte_pos++;
-        }
-        return b;
+    uint32_t len, pos;          // payload length, next byte to load
+    unsigned long long buf;     // next bit = bit 63; bits below the valid ones are 0
+    int cnt;                    // valid (real) bits in buf
+    __device__ __forceinline__ void init(const uint8_t *ptr, uint32_t n) {
+        p = ptr;
+        len = n;
+        pos = 0;
+        buf = 0;
+        cnt = 0;
     }
+    __device__ __forceinline__ void refill() {
+        while (cnt <= 56 && pos < len) {
+            buf |= (unsigned long long)p[pos++] << (56 - cnt);
+            cnt += 8;
+        }
+    }
+    __device__ __forceinline__ void consume(int n) {
+        buf = n >= 64 ? 0ull : buf << n;
+        cnt -= n;
+    }
+    __device__ __forceinline__ bool exhausted() const { return cnt == 0 && pos >= len; }
 };
 
 __device__ __forceinline__ int rice_next(BitRd &r, uint32_t k) {   // one value of decode_i32 (rice.rs:127-155)
     if (r.exhausted()) return 0;
+    // unary quotient: ones until a zero (which is consumed), at most 256 of them (the 256th ends the run without a
+    // terminator), or until the stream runs out
     uint32_t quotient = 0;
-    while (!r.exhausted() && r.bit() == 1u) {
-        quotient++;
-        if (quotient > 255) break;
+    for (;;) {
+        r.refill();
+        if (r.cnt == 0) break;
+        const unsigned long long inv = ~r.buf;
+        int ones = inv ? __clzll((long long)inv) : 64;
+        if (ones > r.cnt) ones = r.cnt;
+        const int room = 256 - (int)quotient;
+        const int take = ones < room ? ones : room;
+        const int before = r.cnt;
+        r.consume(take);
+        quotient += (uint32_t)take;
+        if (quotient == 256u) break;
+        if (take < before) {   // the next real bit is the terminating zero
+            r.consume(1);
+            break;
+        }
     }
+    // k remainder bits, zeros past the end
     uint32_t rem = 0;
-    for (uint32_t i = 0; i < k; i++) rem = (rem << 1) | r.bit();
+    if (k <= 32u) {
+        r.refill();
+        if (k) {
+            rem = (uint32_t)(r.buf >> (64 - k));
+            r.consume((int)k < r.cnt ? (int)k : r.cnt);
+        }
+    } else {
+        for (uint32_t i = 0; i < k; i++) {
+            r.refill();
+            uint32_t bit = 0;
+            if (r.cnt) {
+                bit = (uint32_t)(r.buf >> 63);
+                r.consume(1);
+            }
+            rem = (rem << 1) | bit;
+        }
+    }
     const uint32_t u = (quotient << (k & 31u)) | rem;   // release-mode Rust masks the shift amount
     return (int)(u >> 1) ^ -(int)(u & 1u);
 }
@@ -196,7 +243,8 @@ __global__ __launch_bounds__(64) void ll_decode_kernel(LlDecArgs A) {
     if (!has_coeffs && has_res && c.shift_bits >= 128) {
         // fixed predictor (decoder.rs:186-266): warm-up with lower orders, then binomial recurrences, wrapping adds
         const int order = c.shift_bits - 128;
-        BitRd r{res, c.len, 0, 0};
+        BitRd r;
+        r.init(res, c.len);
         int s1 = 0, s2 = 0, s3 = 0, s4 = 0;   // s[i-1] .. s[i-4]
         for (uint32_t i = 0; i < n; i++) {
             const int rv = rice_next(r, c.rice_k);
@@ -216,7 +264,8 @@ __global__ __launch_bounds__(64) void ll_decode_kernel(LlDecArgs A) {
     if (has_coeffs) {
         // reconstruct_lpc_int (decoder.rs:152-184): the first `order` values are the residuals themselves
         const int order = c.n_coeffs;
-        BitRd r{res, c.len, 0, 0};
+        BitRd r;
+        r.init(res, c.len);
         int hist[12];
 #pragma unroll
         for (int j = 0; j < 12; j++) hist[j] = 0;   // hist[j] = s[i - 1 - j]

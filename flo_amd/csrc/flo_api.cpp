@@ -886,7 +886,7 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
     if (channels) *channels = f.channels;
     const int nch = f.channels;
     DevMem d_bytes;
-    HIPCHK(c, hipMalloc(&d_bytes.p, len ? len : 16));
+    HIPCHK(c, hipMalloc(&d_bytes.p, len + 32));
     HIPCHK(c, hipMemcpyAsync(d_bytes.p, flo, len, hipMemcpyHostToDevice, c->stream));
 
     if (f.is_transform) {

@@ -73,6 +73,33 @@ def test_lossless_special_frames(ctx):
     assert np.array_equal(ctx.decode_lossless_i32(flo), oi)
 
 
+def test_rice_stream_that_runs_out_decodes_like_the_reference(ctx):
+    # corrupt files: a larger Rice parameter makes the decoder consume the payload too fast (it runs out of bits and
+    # pads with zeros, rice.rs:129-133), a smaller one makes it stop early with bits to spare; long unary runs hit
+    # the 256 cap. Whatever the reference decoder makes of such a file, the device decoder must make the same.
+    pcm = signals.music_like(44100, 50000, 2, seed=12)
+    good = ctx.encode_lossless(pcm, 44100, 2, 16, 5)
+    f = flofile.parse(good)
+    data0 = 70 + f.toc_size
+    # first channel of the first frame: [u32 size][u8 n_coef][coefs][u8 shift][u8 enc][u8 k]...
+    ch0 = data0 + 6
+    ncoef = good[ch0 + 4]
+    kpos = ch0 + 4 + 1 + 4 * ncoef + 2
+    assert good[kpos - 1] == 0 and good[kpos] == f.frames[0].channels[0].rice_k
+    for newk in (0, 1, 15, 31, 40):
+        bad = bytearray(good)
+        bad[kpos] = newk
+        oi, _, _ = O.decode_lossless_i32(bytes(bad))
+        assert np.array_equal(ctx.decode_lossless_i32(bytes(bad)), oi), newk
+    # an all-ones payload: every value is the 256-ones escape
+    bad = bytearray(good)
+    size0 = int.from_bytes(good[ch0:ch0 + 4], "little")
+    res0 = kpos + 1
+    bad[res0:ch0 + 4 + size0] = b"\xff" * (ch0 + 4 + size0 - res0)
+    oi, _, _ = O.decode_lossless_i32(bytes(bad))
+    assert np.array_equal(ctx.decode_lossless_i32(bytes(bad)), oi)
+
+
 def test_level0_files_decode_like_the_reference_not_like_the_input(ctx):
     # the Raw-labelled Rice quirk: the reference cannot decode its own level-0 output; neither may we
     pcm = signals.music_like(44100, 30000, 2, seed=3)
