@@ -325,18 +325,8 @@ __device__ __forceinline__ void load_half_fast(const int lane, const float *__re
             ho[0][r] = b.x;
             ho[CH - 1][r] = b.y;
         } else {
-#ifdef FLO_FAKE_LOADS   // diagnostic: issue only a quarter of the loads (results are wrong, timing only)
-            if (r < 2) {
-                he[0][r] = *reinterpret_cast<const float *>(base + be);
-                ho[0][r] = *reinterpret_cast<const float *>(base + bo);
-            } else {
-                he[0][r] = he[0][r & 1];
-                ho[0][r] = ho[0][r & 1];
-            }
-#else
             he[0][r] = *reinterpret_cast<const float *>(base + be);
             ho[0][r] = *reinterpret_cast<const float *>(base + bo);
-#endif
         }
     }
 }

@@ -1,13 +1,16 @@
 // lossy_kernels.hip — gfx950 kernels of the lossy encode path and their launchers.
 //
-//   lossy_chain_kernel<CH>   one wavefront per clip walks the clip's frames in order (the psychoacoustic
+//   lossy_chain3_kernel      stereo batches (the default): two channel wavefronts per clip run transform, masking
+//                            and quantiser of frame t + 1 while a packer wavefront serialises and flushes frame t.
+//   lossy_chain_kernel<NW>   one wavefront per (clip, channel) walks the clip's frames in order (the psychoacoustic
 //                            model's 25-float temporal state, psychoacoustic.rs:198-203, lives in registers),
 //                            reads every PCM sample once and appends finished frame bytes to the clip's DATA
 //                            chunk: replaces the hot loop of TransformEncoder::encode_to_flo (encoder.rs:200-225).
 //   lossy_frame_kernel<CH,P> frame-parallel form for few/long clips: P=1 computes only the per-band masking
 //                            level before temporal masking, lossy_scan_kernel resolves the recurrence, P=2
 //                            re-runs the transform and finishes each frame into a fixed slot; compact_kernel
-//                            packs the slots. Both forms produce identical bytes.
+//                            packs the slots. lossy_frame_n_kernel<P> is the same for 3 to 8 channels.
+//   All forms produce identical bytes (tests compare them file by file).
 #include "lossy_device.hpp"
 #include "lossy_kernels.hpp"
 #include "../../include/flo_synth.h"
