@@ -482,6 +482,7 @@ static LossyArgs make_args(flo_batch *b) {
 extern "C" int flo_batch_encode(flo_batch *b, int which) {
     if (!b) return FLO_ERR_ARG;
     flo_ctx *c = b->ctx;
+    if (which < 0 || which > 3) return fail(c, FLO_ERR_ARG, "unknown kernel form");
     HIPCHK(c, hipSetDevice(c->device));
     b->encoded = true;
     b->synced = false;

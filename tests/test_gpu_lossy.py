@@ -330,3 +330,38 @@ def test_more_than_two_channels(ctx, ch):
         assert dg.shape == do.shape and np.max(np.abs(dg - do)) <= 2e-6
     with pytest.raises(Exception):
         ctx.encode_lossy(signals.music_like(sr, 2000, 9, seed=1), sr, 9, 0.55)
+
+
+def test_api_misuse_is_reported_not_crashed(ctx):
+    import torch
+    import flo_amd
+    b = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [2048 * 2, 4096 * 2], 44100, 2, 0.55)
+    with pytest.raises(flo_amd.FloError, match="flo_batch_encode"):
+        b.fetch(0)                                      # nothing encoded yet
+    with pytest.raises(flo_amd.FloError, match="flo_batch_encode"):
+        b.pack_files(0, 0)
+    b.fill_synthetic()
+    b.encode(0)
+    with pytest.raises(flo_amd.FloError, match="flo_batch_encode"):
+        b.fetch(0)                                      # encoded but not synced
+    b.sync()
+    small = torch.empty(64, dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(flo_amd.FloError, match="too small"):
+        b.pack_files(small.data_ptr(), small.numel())
+    with pytest.raises(flo_amd.FloError, match="too small"):
+        b.decode_to(small.data_ptr(), 1)
+    with pytest.raises(flo_amd.FloError):
+        b.encode(7)                                     # unknown kernel form
+    assert flofile.parse(b.fetch(1)).crc_valid          # the batch is still usable
+    b.close()
+    with pytest.raises(flo_amd.FloError):
+        flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [100], 0, 2, 0.55)       # sample_rate 0
+    with pytest.raises(flo_amd.FloError):
+        flo_amd.Batch(ctx, 5, [100], 44100, 2, 0.55)                    # unknown mode
+    lb = flo_amd.Batch(ctx, flo_amd.MODE_LOSSLESS, [1000], 44100, 2, 5)
+    lb.fill_synthetic()
+    lb.encode(0)
+    lb.sync()
+    with pytest.raises(flo_amd.FloError, match="lossy"):
+        lb.decode_to(small.data_ptr(), small.numel())
+    lb.close()
