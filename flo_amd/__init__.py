@@ -5,4 +5,4 @@ this package is only the host-side mirror of the reference's encoder interface.
 """
 from ._native import FloError, MODE_LOSSLESS, MODE_LOSSY  # noqa: F401
 from .api import (Batch, Context, Decoder, Encoder, LossyEncoder, QualityPreset, TransformEncoder, default_context,  # noqa: F401
-                  decode, encode, encode_lossy, encode_with_bitrate)
+                  decode, encode, encode_lossy, encode_with_bitrate, probe_container)

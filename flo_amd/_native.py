@@ -17,7 +17,7 @@ MODE_LOSSLESS, MODE_LOSSY = 0, 1
 
 EXPORTS = [
     "flo_ctx_create", "flo_ctx_destroy", "flo_last_error", "flo_last_create_error", "flo_free", "flo_ctx_device_info",
-    "flo_encode_lossy", "flo_encode_lossless", "flo_encode_batch", "flo_decode", "flo_decode_lossless_i32",
+    "flo_encode_lossy", "flo_encode_lossless", "flo_encode_batch", "flo_decode", "flo_decode_lossless_i32", "flo_probe_container",
     "flo_batch_create", "flo_batch_destroy", "flo_batch_clip_device_ptr", "flo_batch_upload",
     "flo_batch_fill_synthetic", "flo_batch_encode", "flo_batch_sync", "flo_batch_data_bytes", "flo_batch_fetch",
     "flo_batch_device_streams", "flo_batch_pack_streams", "flo_batch_decode",
@@ -25,6 +25,14 @@ EXPORTS = [
     "flo_ctx_profile_enable", "flo_ctx_profile_query", "flo_ctx_profile_reset", "flo_ctx_force_path", "flo_ctx_stream",
     "flo_mdct_forward", "flo_lossy_analyze", "flo_lossy_quantize", "flo_sparse_pack",
 ]
+
+
+class ContainerInfo(C.Structure):
+    _fields_ = [("version_major", C.c_uint8), ("version_minor", C.c_uint8), ("channels", C.c_uint8), ("bit_depth", C.c_uint8),
+                ("compression_level", C.c_uint8), ("is_transform", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_uint8),
+                ("flags", C.c_uint16), ("pad2", C.c_uint16), ("sample_rate", C.c_uint32), ("data_crc32", C.c_uint32),
+                ("n_frames", C.c_uint32), ("total_samples", C.c_uint64), ("data_start", C.c_uint64), ("data_size", C.c_uint64),
+                ("frame_samples_sum", C.c_uint64)]
 
 
 class FloError(RuntimeError):
@@ -91,5 +99,6 @@ def lib():
     L.flo_sparse_pack.argtypes = [vp, vp, sz, vp, sz, vp]
     L.flo_decode.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
     L.flo_decode_lossless_i32.argtypes = L.flo_decode.argtypes
+    L.flo_probe_container.argtypes = [C.c_char_p, sz, C.POINTER(ContainerInfo), C.c_char_p, sz]
     _LIB = L
     return L

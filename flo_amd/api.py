@@ -344,6 +344,18 @@ class TransformEncoder:
 LossyEncoder = TransformEncoder
 
 
+def probe_container(data: bytes):
+    """Header and frame census of a .flo file as the container reader sees it (reader.rs:16-256); no device needed.
+    Raises FloError with the reader's message for files the reference reader rejects."""
+    L = _native.lib()
+    info = _native.ContainerInfo()
+    err = C.create_string_buffer(256)
+    data = bytes(data)
+    if L.flo_probe_container(data, len(data), C.byref(info), err, len(err)) != 0:
+        raise FloError(err.value.decode() or "not a .flo file")
+    return info
+
+
 def decode(data: bytes):
     """libflo::decode (lib.rs:296-315)"""
     return default_context().decode(data)

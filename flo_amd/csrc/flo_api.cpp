@@ -872,6 +872,33 @@ int upload(flo_ctx *c, DevMem &m, const std::vector<T> &v) {
 }
 }  // namespace
 
+extern "C" int flo_probe_container(const uint8_t *flo, size_t len, flo_container_info *out, char *err, size_t err_cap) {
+    if (!out || (!flo && len)) return FLO_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    if (err && err_cap) err[0] = 0;
+    ParsedFile f;
+    const char *perr = "";
+    if (parse_file(flo, len, f, &perr) != 0) {
+        if (err && err_cap) snprintf(err, err_cap, "%s", perr);
+        return FLO_ERR_FORMAT;
+    }
+    out->version_major = f.version_major;
+    out->version_minor = f.version_minor;
+    out->channels = f.channels;
+    out->bit_depth = f.bit_depth;
+    out->compression_level = f.compression_level;
+    out->is_transform = f.is_transform ? 1 : 0;
+    out->flags = f.flags;
+    out->sample_rate = f.sample_rate;
+    out->data_crc32 = f.data_crc32;
+    out->n_frames = (uint32_t)f.frames.size();
+    out->total_samples = f.total_samples;
+    out->data_start = f.data_start;
+    out->data_size = f.data_size;
+    for (const FrameDesc &fr : f.frames) out->frame_samples_sum += fr.samples;
+    return FLO_OK;
+}
+
 // libflo::decode (lib.rs:296-315): parse on the host (a few bytes per frame), decode on the device.
 static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, int32_t **pcm_i32, size_t *n_interleaved,
                        uint32_t *sample_rate, uint8_t *channels) {

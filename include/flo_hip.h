@@ -78,6 +78,22 @@ int flo_decode(flo_ctx *ctx, const uint8_t *flo, size_t len, float **pcm, size_t
 int flo_decode_lossless_i32(flo_ctx *ctx, const uint8_t *flo, size_t len, int32_t **pcm, size_t *n_interleaved,
                             uint32_t *sample_rate, uint8_t *channels);
 
+/* What the container reader (Reader::read, reader.rs:16-256) extracts from a file, without touching the device: the
+ * host half of flo_decode on its own. Returns FLO_OK or FLO_ERR_FORMAT with the reader's message in err (may be NULL,
+ * err_cap bytes). No context needed. */
+typedef struct flo_container_info {
+    uint8_t version_major, version_minor, channels, bit_depth;
+    uint8_t compression_level, is_transform, pad0, pad1;
+    uint16_t flags, pad2;
+    uint32_t sample_rate;
+    uint32_t data_crc32;
+    uint32_t n_frames;          /* frames the reader accepted */
+    uint64_t total_samples;     /* header field */
+    uint64_t data_start, data_size;
+    uint64_t frame_samples_sum; /* sum of frame_samples over the frames read */
+} flo_container_info;
+int flo_probe_container(const uint8_t *flo, size_t len, flo_container_info *out, char *err, size_t err_cap);
+
 /* ---- device-resident batch (the throughput path: PCM already in HBM, bitstreams left in HBM) -------- */
 typedef struct flo_batch flo_batch;
 
