@@ -229,3 +229,34 @@ def test_full_size_configs_round_trip_on_the_device(ctx, n_clips, seconds, q):
     g_dec = dec[0].cpu().numpy()
     assert abs(snr_db(pcm0, o_dec[: pcm0.size]) - snr_db(pcm0, g_dec)) < 0.05
     b.close()
+
+
+def test_damaged_transform_payloads_decode_like_the_oracle_or_fail_like_it(ctx):
+    # single-byte damage anywhere in the DATA chunk of a lossy file: record headers, varints, counts, scale words,
+    # blob lengths. Whatever the reference decoder does with such a file - error, or garbage - the device does too.
+    pcm = signals.music_like(44100, 20000, 2, seed=31)
+    good = ctx.encode_lossy(pcm, 44100, 2, 0.8)
+    f = flofile.parse(good)
+    d0 = 70 + f.toc_size
+    rng = np.random.default_rng(7)
+    spots = [int(x) for x in rng.integers(d0, d0 + f.data_size, 120)] + list(range(d0, d0 + 140))
+    errors = same = 0
+    for pos in spots:
+        bad = bytearray(good)
+        bad[pos] ^= int(rng.integers(1, 256))
+        bad = bytes(bad)
+        try:
+            o, _, _ = O.decode(bad)
+        except RuntimeError:
+            with pytest.raises(flo_amd.FloError):
+                ctx.decode(bad)
+            errors += 1
+            continue
+        g = ctx.decode(bad)
+        assert g.shape == o.shape, pos
+        fin = np.isfinite(o) & np.isfinite(g)
+        assert np.array_equal(np.isfinite(o), np.isfinite(g)) or (~fin).sum() < 4096, pos
+        scale = max(1.0, float(np.max(np.abs(o[fin]), initial=0.0)))
+        assert np.max(np.abs(g[fin] - o[fin]), initial=0.0) <= 4e-6 * scale, pos
+        same += 1
+    assert errors > 5 and same > 50
