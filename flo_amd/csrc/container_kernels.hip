@@ -7,6 +7,9 @@
 #include "container_kernels.hpp"
 
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace flo {
 
@@ -40,6 +43,13 @@ __device__ __forceinline__ uint32_t x8n_tab(const unsigned int (&pow2)[40], unsi
     for (int j = 0; n; j++, n >>= 1)
         if (n & 1ull) p = multmodp(pow2[j], p);
     return p;
+}
+
+// x^(8 n) mod P from three tables when n < 4 MiB (two products), else bit by bit
+__device__ __forceinline__ uint32_t x8n_fast(const FinishArgs &A, unsigned long long n) {
+    if (n >= (256ull << 14)) return x8n_tab(A.x8pow2, n);
+    const uint32_t a = A.stripe_pow[n >> 14], b = A.blk_pow[(n >> 6) & 255u], c = A.byte_pow[n & 63u];
+    return multmodp(multmodp(a, b), c);
 }
 
 __device__ __forceinline__ void put8(uint8_t *p, unsigned v) { *p = (uint8_t)v; }
@@ -84,27 +94,18 @@ __global__ __launch_bounds__(kFinThreads) void crc_slices_kernel(FinishArgs A) {
     }
     const uint8_t *data = A.out + A.data_off[clip] + beg;
 
-    {   // crc32.rs:2-20 builds the first byte table the same way
-        uint32_t c = t;
-        for (int j = 0; j < 8; j++) c = (c & 1u) ? (c >> 1) ^ kPoly : c >> 1;
-        tab[0][t] = c;
-    }
-    __syncthreads();
-    {
-        uint32_t c = tab[0][t];
-        for (int k = 1; k < 4; k++) {
-            c = tab[0][c & 0xFFu] ^ (c >> 8);
-            tab[k][t] = c;
-        }
-        for (int k = 0; k < 4; k++) skip[k][t] = multmodp(A.skip, t << (8 * k));
+    // byte tables (crc32.rs:2-20 builds the first one the same way) and the skip table, made once on the host
+    for (int k = 0; k < 4; k++) {
+        tab[k][t] = A.tables[k * 256 + t];
+        skip[k][t] = A.tables[1024 + k * 256 + t];
     }
     const unsigned long long full = n / kStripe;          // complete stripes
     const unsigned long long rem0 = full * kStripe;       // first byte behind them
     const unsigned rem = (unsigned)(n - rem0);
     const unsigned nb = rem / kBlk, last = rem % kBlk;
-    // two per-slice powers, each by the first lane of a different wave: x^(8 rem), x^(8 last)
-    if (t == 0) s_pw[0] = x8n_tab(A.x8pow2, rem);
-    if (t == 64) s_pw[1] = x8n_tab(A.x8pow2, last);
+    // two per-slice powers from the tables: x^(8 rem) = x^(8 * 64 * nb) * x^(8 last), and x^(8 last)
+    if (t == 0) s_pw[0] = multmodp(A.blk_pow[nb], A.byte_pow[last]);
+    if (t == 64) s_pw[1] = A.byte_pow[last];
     __syncthreads();
     auto eat = [&](uint32_t reg, const uint8_t *p, unsigned bytes) {   // bytes is a multiple of 4, p 4-byte aligned
         for (unsigned i = 0; i < bytes; i += 4) {
@@ -172,9 +173,9 @@ __global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A)
         if (t < A.parts) {
             const unsigned long long end = (unsigned long long)(t + 1) * S < n ? (unsigned long long)(t + 1) * S : n;
             const unsigned long long beg = (unsigned long long)t * S < n ? (unsigned long long)t * S : n;
-            if (end > beg) acc = multmodp(x8n_tab(A.x8pow2, n - end), A.part_reg[(unsigned long long)clip * A.parts + t]);
+            if (end > beg) acc = multmodp(x8n_fast(A, n - end), A.part_reg[(unsigned long long)clip * A.parts + t]);
         } else if (t == A.parts) {
-            acc = multmodp(x8n_tab(A.x8pow2, n), 0xFFFFFFFFu);
+            acc = multmodp(x8n_fast(A, n), 0xFFFFFFFFu);
         }
     }
     for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_down(acc, d);
@@ -244,16 +245,49 @@ __global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A)
 int launch_finish_files(FinishArgs A, hipStream_t s) {
     if (!A.n_clips) return 0;
     if (A.parts < 1 || A.parts > 128 || !A.part_reg) return -1;
-    static unsigned int pow2[40], blk[256], skip = 0;
-    if (!skip) {
-        uint32_t p = 0x00800000u;   // x^8
-        for (int j = 0; j < 40; j++, p = multmodp(p, p)) pow2[j] = p;
-        for (int i = 0; i < 256; i++) blk[i] = x8n_modp(64ull * i);
-        skip = x8n_modp(kStripe - kBlk);
+    static unsigned int pow2[40], blk[256], bytep[64], stripep[256];
+    static std::vector<unsigned int> host_tables;
+    static std::mutex mu;
+    static std::map<int, unsigned int *> dev_tables;   // one copy per device, made on first use, kept for the process
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (host_tables.empty()) {
+            uint32_t p = 0x00800000u;   // x^8
+            for (int j = 0; j < 40; j++, p = multmodp(p, p)) pow2[j] = p;
+            for (int i = 0; i < 256; i++) blk[i] = x8n_modp(64ull * i);
+            for (int i = 0; i < 64; i++) bytep[i] = x8n_modp((unsigned long long)i);
+            for (int i = 0; i < 256; i++) stripep[i] = x8n_modp((unsigned long long)i << 14);
+            host_tables.resize(2048);
+            for (uint32_t i = 0; i < 256; i++) {
+                uint32_t c = i;
+                for (int j = 0; j < 8; j++) c = (c & 1u) ? (c >> 1) ^ kPoly : c >> 1;
+                host_tables[i] = c;
+            }
+            for (uint32_t i = 0; i < 256; i++) {
+                uint32_t c = host_tables[i];
+                for (int k = 1; k < 4; k++) {
+                    c = host_tables[c & 0xFFu] ^ (c >> 8);
+                    host_tables[k * 256 + i] = c;
+                }
+            }
+            const uint32_t skipm = x8n_modp(kStripe - kBlk);
+            for (int k = 0; k < 4; k++)
+                for (uint32_t i = 0; i < 256; i++) host_tables[1024 + k * 256 + i] = multmodp(skipm, i << (8 * k));
+        }
+        if (!dev_tables.count(dev)) {
+            unsigned int *d = nullptr;
+            if (hipMalloc(&d, host_tables.size() * 4) != hipSuccess) return -1;
+            if (hipMemcpy(d, host_tables.data(), host_tables.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return -1;
+            dev_tables[dev] = d;
+        }
+        A.tables = dev_tables[dev];
     }
     memcpy(A.x8pow2, pow2, sizeof pow2);
     memcpy(A.blk_pow, blk, sizeof blk);
-    A.skip = skip;
+    memcpy(A.byte_pow, bytep, sizeof bytep);
+    memcpy(A.stripe_pow, stripep, sizeof stripep);
     hipLaunchKernelGGL(crc_slices_kernel, dim3(A.parts, (unsigned)A.n_clips), dim3(kFinThreads), 0, s, A);
     hipLaunchKernelGGL(finish_files_kernel, dim3((unsigned)A.n_clips), dim3(kFinThreads), 0, s, A);
     hipError_t e = hipGetLastError();

@@ -25,8 +25,10 @@ struct FinishArgs {
     unsigned int *part_reg;                 // [n_clips * parts] scratch: CRC register of every slice
     // powers of x modulo the CRC polynomial (reflected), filled in by launch_finish_files
     unsigned int x8pow2[40];                // x^(8 * 2^j)
-    unsigned int skip;                      // x^(8 * (16384 - 64)): from one 64-byte block of a thread to its next
     unsigned int blk_pow[256];              // x^(8 * 64 * i)
+    unsigned int byte_pow[64];              // x^(8 * i)
+    unsigned int stripe_pow[256];           // x^(8 * 16384 * i)
+    const unsigned int *tables;             // device: tab[4][256] byte tables, then skip[4][256] (times x^(8 * 16320))
 };
 
 int launch_finish_files(FinishArgs A, hipStream_t s);
