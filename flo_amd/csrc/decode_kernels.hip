@@ -20,139 +20,176 @@ __device__ __forceinline__ uint32_t rd_u32(const uint8_t *p) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
+// One wavefront decodes a run of kDecRun consecutive output blocks of one clip: output block b (1024 sample-frames) is
+// the first half of frame b + 1 plus the second half of frame b (mdct.rs:449-456; the first frame's own block is
+// dropped, lib.rs:338-341), so the run needs kDecRun + 1 frames and keeps the previous frame's second half in LDS.
+// Every output sample is written exactly once, by plain stores.
+constexpr int kDecRun = 8;
+constexpr int kBlobStage = 2304;
+
 __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
     __shared__ short q[1024];
     __shared__ float xch[1][kXchFloats];
     __shared__ float recon[2048];
+    __shared__ float prev[1024];                // second half of the previous frame of the channel being walked
     __shared__ uint32_t rec_pos[kMaxRecords];   // output index | count << 16 (count <= 255, index < 1024)
     __shared__ uint32_t rec_src[kMaxRecords];   // byte position of the record's first value
     __shared__ float sf[32];
     __shared__ int s_nrec;
+    __shared__ __attribute__((aligned(16))) uint8_t sblob[kBlobStage + 16];   // the channel's sparse bytes, staged
     const int lane = (int)threadIdx.x;
-    const unsigned clip = blockIdx.y, h = blockIdx.x;
-    if (clip >= (unsigned)D.n_clips || h >= D.clip_frames[clip]) return;
-    const unsigned long long f = D.clip_frame0[clip] + h;
-    const uint8_t *data = D.bytes + D.blob_off[f];
-    const uint32_t len = D.blob_len[f];
+    const unsigned clip = blockIdx.y;
+    if (clip >= (unsigned)D.n_clips) return;
     const unsigned nframes = D.clip_frames[clip];
+    const unsigned h0 = blockIdx.x * kDecRun;          // first frame of the run = first output block
+    if (nframes < 2 || h0 + 1 >= nframes) return;
+    const unsigned h1 = h0 + kDecRun < nframes - 1 ? h0 + kDecRun : nframes - 1;   // last frame of the run
     float *out = D.out + D.clip_out[clip];
+    const float scale = 2.0f / 1024.0f;
+    const float *win = D.window;
 
-    // deserialize_frame: [block_size][channels][25 x u16 per channel][per channel: u32 len, sparse bytes]
-    if (len < 2 || data[0] != 0 /* only Long blocks are produced or accepted */ || data[1] > D.channels) {
-        if (lane == 0) atomicExch(D.error, 1);
-        return;
-    }
-    const uint32_t nch = data[1];
-    uint32_t pos = 2 + 50 * nch;
-    if (pos > len) {
-        if (lane == 0) atomicExch(D.error, 1);
-        return;
-    }
-    for (uint32_t c = 0; c < nch; c++) {
-        if (pos + 4 > len) {
-            if (lane == 0) atomicExch(D.error, 1);
-            return;
-        }
-        const uint32_t blen = rd_u32(data + pos);
-        pos += 4;
-        if (pos + blen > len || pos + blen < pos) {
-            if (lane == 0) atomicExch(D.error, 1);
-            return;
-        }
-        const uint8_t *sp = data + pos;
-        pos += blen;
-        // scale factors: 2^((word - 32768) / 256), 0 when the word is 0 (decoder.rs:91-99)
-        if (lane < 25) {
-            const uint32_t wv = rd_u16(data + 2 + 50 * c + 2 * lane);
-            sf[lane] = wv > 0 ? powf(2.0f, ((float)wv - 32768.0f) / 256.0f) : 0.0f;
-        }
-        for (int i = lane; i < 1024; i += 64) q[i] = 0;
-        // deserialize_sparse (decoder.rs:134-167): lane 0 walks the record headers, then every lane copies records
-        if (lane == 0) {
-            uint32_t p = 0, nrec = 0;
-            unsigned long long oi = 0;
-            while (p < blen && oi < 1024) {
-                uint32_t value = 0, shift = 0;
-                while (p < blen) {   // decode_varint (:170-188)
-                    const uint32_t b = sp[p++];
-                    value |= (b & 0x7Fu) << shift;
-                    if (!(b & 0x80u)) break;
-                    shift += 7;
-                    if (shift >= 32) break;
-                }
-                oi += value;
-                if (p >= blen) break;
-                const uint32_t nz = sp[p++];
-                const uint32_t avail = (blen - p) >> 1;
-                const uint32_t room = oi < 1024 ? (uint32_t)(1024 - oi) : 0u;
-                uint32_t cnt = nz < avail ? nz : avail;
-                cnt = cnt < room ? cnt : room;
-                if (cnt && nrec < kMaxRecords) {
-                    rec_pos[nrec] = (uint32_t)oi | (cnt << 16);
-                    rec_src[nrec] = p;
-                    nrec++;
-                }
-                p += 2 * cnt;
-                oi += cnt;
+    for (uint32_t c = 0; c < (uint32_t)D.channels; c++) {
+        for (int j = lane; j < 1024; j += 64) prev[j] = 0.0f;
+        for (unsigned h = h0; h <= h1; h++) {
+            const unsigned long long f = D.clip_frame0[clip] + h;
+            const uint8_t *data = D.bytes + D.blob_off[f];
+            const uint32_t len = D.blob_len[f];
+            // deserialize_frame: [block_size][channels][25 x u16 per channel][per channel: u32 len, sparse bytes]
+            if (len < 2 || data[0] != 0 /* only Long blocks are produced or accepted */ || data[1] > D.channels) {
+                if (lane == 0) atomicExch(D.error, 1);
+                return;
             }
-            s_nrec = (int)nrec;
-        }
-        __syncthreads();
-        for (int r = lane; r < s_nrec; r += 64) {
-            const uint32_t o = rec_pos[r] & 0xFFFFu, cnt = rec_pos[r] >> 16;
-            const uint8_t *v = sp + rec_src[r];
-            for (uint32_t i = 0; i < cnt; i++) q[o + i] = (short)rd_u16(v + 2 * i);
-        }
-        __syncthreads();
-        // dequantise (decoder.rs:35-48) straight into the inverse transform's pre-rotation (mdct.rs:238-247)
-        float zr[1][8], zi[1][8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int i = lane + 64 * r;
-            const int ke = 2 * i, ko = 1023 - 2 * i;
-            const float se = sf[D.T.band[ke]], so = sf[D.T.band[ko]];
-            const float even = se > 0.0f ? __fdiv_rn((float)q[ke], se) : 0.0f;
-            const float odd = -(so > 0.0f ? __fdiv_rn((float)q[ko], so) : 0.0f);
-            const float4 t4 = D.T.pack[(8 + (r >> 1)) * 64 + lane];
-            const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
-            zr[0][r] = odd * w.y - even * w.x;
-            zi[0][r] = odd * w.x + even * w.y;
-        }
-        fft512<1>(lane, zr, zi, xch, D.T);
-        // post-rotation, scale 2 / 1024 and window (mdct.rs:252-287); every output position is written exactly once
-        const float scale = 2.0f / 1024.0f;
-        const float *win = D.window;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int idx = lane + 64 * r;
-            const float4 t4 = D.T.pack[(8 + (r >> 1)) * 64 + lane];
-            const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
-            const float val_re = w.x * zr[0][r] + w.y * zi[0][r];
-            const float val_im = w.y * zr[0][r] - w.x * zi[0][r];
-            if (idx < 256) {
-                const int fi = 2 * idx, ri = 511 - 2 * idx;
-                recon[ri] = -val_im * scale * win[ri];
-                recon[512 + fi] = val_im * scale * win[512 + fi];
-                recon[1024 + ri] = val_re * scale * win[1024 + ri];
-                recon[1536 + fi] = val_re * scale * win[1536 + fi];
-            } else {
-                const int i2 = idx - 256;
-                const int fi = 2 * i2, ri = 511 - 2 * i2;
-                recon[fi] = -val_re * scale * win[fi];
-                recon[512 + ri] = val_re * scale * win[512 + ri];
-                recon[1024 + fi] = val_im * scale * win[1024 + fi];
-                recon[1536 + ri] = val_im * scale * win[1536 + ri];
+            const uint32_t nch = data[1];
+            uint32_t pos = 2 + 50 * nch;
+            bool bad = pos > len;
+            uint32_t blen = 0;
+            for (uint32_t k = 0; k <= c && k < nch && !bad; k++) {   // walk to channel c's sparse blob
+                if (pos + 4 > len) {
+                    bad = true;
+                    break;
+                }
+                blen = rd_u32(data + pos);
+                pos += 4;
+                if (pos + blen > len || pos + blen < pos) {
+                    bad = true;
+                    break;
+                }
+                if (k < c) pos += blen;
             }
+            if (bad) {
+                if (lane == 0) atomicExch(D.error, 1);
+                return;
+            }
+            const bool present = c < nch;      // a frame with fewer channels leaves the others silent
+            if (present) {
+                // the record walk below is a chain of dependent byte reads: from LDS it costs a tenth of what it
+                // costs from global memory. Valid blobs are at most ~2.1 KB; anything longer is walked in place.
+                const uint8_t *sp = data + pos;
+                if (blen <= (uint32_t)kBlobStage) {
+                    for (uint32_t i = 4u * lane; i < blen; i += 256u) {
+                        uint32_t w4;
+                        __builtin_memcpy(&w4, sp + i, 4);   // up to 3 bytes past the blob: inside the file + slack
+                        *reinterpret_cast<uint32_t *>(sblob + i) = w4;
+                    }
+                    __syncthreads();
+                    sp = sblob;
+                }
+                // scale factors: 2^((word - 32768) / 256), 0 when the word is 0 (decoder.rs:91-99)
+                if (lane < 25) {
+                    const uint32_t wv = rd_u16(data + 2 + 50 * c + 2 * lane);
+                    sf[lane] = wv > 0 ? powf(2.0f, ((float)wv - 32768.0f) / 256.0f) : 0.0f;
+                }
+                for (int i = lane; i < 1024; i += 64) q[i] = 0;
+                // deserialize_sparse (decoder.rs:134-167): lane 0 walks the record headers, then every lane copies records
+                if (lane == 0) {
+                    uint32_t p = 0, nrec = 0;
+                    unsigned long long oi = 0;
+                    while (p < blen && oi < 1024) {
+                        uint32_t value = 0, shift = 0;
+                        while (p < blen) {   // decode_varint (:170-188)
+                            const uint32_t b = sp[p++];
+                            value |= (b & 0x7Fu) << shift;
+                            if (!(b & 0x80u)) break;
+                            shift += 7;
+                            if (shift >= 32) break;
+                        }
+                        oi += value;
+                        if (p >= blen) break;
+                        const uint32_t nz = sp[p++];
+                        const uint32_t avail = (blen - p) >> 1;
+                        const uint32_t room = oi < 1024 ? (uint32_t)(1024 - oi) : 0u;
+                        uint32_t cnt = nz < avail ? nz : avail;
+                        cnt = cnt < room ? cnt : room;
+                        if (cnt && nrec < kMaxRecords) {
+                            rec_pos[nrec] = (uint32_t)oi | (cnt << 16);
+                            rec_src[nrec] = p;
+                            nrec++;
+                        }
+                        p += 2 * cnt;
+                        oi += cnt;
+                    }
+                    s_nrec = (int)nrec;
+                }
+                __syncthreads();
+                for (int r = lane; r < s_nrec; r += 64) {
+                    const uint32_t o = rec_pos[r] & 0xFFFFu, cnt = rec_pos[r] >> 16;
+                    const uint8_t *v = sp + rec_src[r];
+                    for (uint32_t i = 0; i < cnt; i++) q[o + i] = (short)rd_u16(v + 2 * i);
+                }
+                __syncthreads();
+                // dequantise (decoder.rs:35-48) straight into the inverse transform's pre-rotation (mdct.rs:238-247)
+                float zr[1][8], zi[1][8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int i = lane + 64 * r;
+                    const int ke = 2 * i, ko = 1023 - 2 * i;
+                    const float se = sf[D.T.band[ke]], so = sf[D.T.band[ko]];
+                    const float even = se > 0.0f ? __fdiv_rn((float)q[ke], se) : 0.0f;
+                    const float odd = -(so > 0.0f ? __fdiv_rn((float)q[ko], so) : 0.0f);
+                    const float4 t4 = D.T.pack[(8 + (r >> 1)) * 64 + lane];
+                    const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
+                    zr[0][r] = odd * w.y - even * w.x;
+                    zi[0][r] = odd * w.x + even * w.y;
+                }
+                fft512<1>(lane, zr, zi, xch, D.T);
+                // post-rotation, scale 2 / 1024 and window (mdct.rs:252-287); every position is written exactly once
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int idx = lane + 64 * r;
+                    const float4 t4 = D.T.pack[(8 + (r >> 1)) * 64 + lane];
+                    const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
+                    const float val_re = w.x * zr[0][r] + w.y * zi[0][r];
+                    const float val_im = w.y * zr[0][r] - w.x * zi[0][r];
+                    if (idx < 256) {
+                        const int fi = 2 * idx, ri = 511 - 2 * idx;
+                        recon[ri] = -val_im * scale * win[ri];
+                        recon[512 + fi] = val_im * scale * win[512 + fi];
+                        recon[1024 + ri] = val_re * scale * win[1024 + ri];
+                        recon[1536 + fi] = val_re * scale * win[1536 + fi];
+                    } else {
+                        const int i2 = idx - 256;
+                        const int fi = 2 * i2, ri = 511 - 2 * i2;
+                        recon[fi] = -val_re * scale * win[fi];
+                        recon[512 + ri] = val_re * scale * win[512 + ri];
+                        recon[1024 + fi] = val_im * scale * win[1024 + fi];
+                        recon[1536 + ri] = val_im * scale * win[1536 + ri];
+                    }
+                }
+                __syncthreads();
+            }
+            // overlap-add (mdct.rs:449-456): block h - 1 = first half of this frame + second half of the previous one.
+            // A channel the frame does not carry gives a silent block and leaves its overlap buffer alone (the
+            // reference would fail on such a frame; the oracle behaves like this).
+            if (h > h0) {
+                for (int j = lane; j < 1024; j += 64) {
+                    const float a = present ? recon[j] + prev[j] : 0.0f;
+                    out[((unsigned long long)(h - 1) * 1024 + j) * D.channels + c] = a;
+                }
+            }
+            if (present)
+                for (int j = lane; j < 1024; j += 64) prev[j] = recon[1024 + j];
+            __syncthreads();
         }
-        __syncthreads();
-        // overlap-add (mdct.rs:449-456): output block h - 1 = first half of frame h + second half of frame h - 1.
-        // Each output sample receives exactly two contributions onto a zero: the float sum does not depend on order.
-        // The first frame's block is dropped (lib.rs:338-341), the last frame's second half is never emitted.
-        for (int j = lane; j < 1024; j += 64) {
-            if (h >= 1) atomicAdd(out + ((unsigned long long)(h - 1) * 1024 + j) * D.channels + c, recon[j]);
-            if (h + 1 < nframes) atomicAdd(out + ((unsigned long long)h * 1024 + j) * D.channels + c, recon[1024 + j]);
-        }
-        __syncthreads();
     }
 }
 
@@ -328,8 +365,9 @@ __global__ __launch_bounds__(256) void ll_finish_kernel(LlFinishArgs A) {
     } while (0)
 
 int launch_lossy_decode(const LossyDecArgs &A, unsigned max_frames, hipStream_t s) {
-    if (!max_frames || !A.n_clips) return 0;
-    hipLaunchKernelGGL(lossy_decode_kernel, dim3(max_frames, (unsigned)A.n_clips), dim3(64), 0, s, A);
+    if (max_frames < 2 || !A.n_clips) return 0;
+    const unsigned runs = (max_frames - 1 + kDecRun - 1) / kDecRun;
+    hipLaunchKernelGGL(lossy_decode_kernel, dim3(runs, (unsigned)A.n_clips), dim3(64), 0, s, A);
     FLO_LAUNCH_CHECK();
     return 0;
 }
