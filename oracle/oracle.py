@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_SO_OVERRIDE = None   # tests/test_sanitizers.py points this at the ASan/UBSan build before the first call
 
 
 def build(force=False):
@@ -36,7 +37,7 @@ class Info(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        L = C.CDLL(_SO_OVERRIDE or build())
         u8p, f32p, i32p, i16p, i64p = (C.POINTER(t) for t in (C.c_uint8, C.c_float, C.c_int32, C.c_int16, C.c_int64))
         L.flo_o_free.argtypes = [C.c_void_p]
         L.flo_o_crc32.restype = C.c_uint32
