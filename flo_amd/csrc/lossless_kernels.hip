@@ -318,7 +318,10 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
     // before them in registers (kWin), so every predictor tap of every candidate is a register operand: the plane is
     // read once per sweep instead of once per tap. Every statistic is an exact integer sum or maximum, so how the
     // samples are dealt to threads cannot change a result.
-    constexpr int kRun = 16, kHist = kMaxOrder, kWin = kRun + kHist;
+#ifndef FLO_LL_RUN
+#define FLO_LL_RUN 16
+#endif
+    constexpr int kRun = FLO_LL_RUN, kHist = kMaxOrder, kWin = kRun + kHist;
     const unsigned int tile = kLLThreads * kRun;
     auto load_window = [&](unsigned int i0, int (&w)[kWin]) {
 #pragma unroll
