@@ -269,8 +269,13 @@ __device__ __forceinline__ int rice_next(BitRd &r, uint32_t k) {   // one value 
     return (int)(u >> 1) ^ -(int)(u & 1u);
 }
 
+// SPREAD = 1: one channel wrapper per wavefront (lane 0 only). The walk is serial and data-dependent, so lanes of one
+// wave that decode different streams execute the union of their paths (measured: 380 instructions per sample with 20
+// lanes against ~150 alone); with few wrappers (a single file) a wave each is faster, with many the lanes are needed.
+template <int SPREAD>
 __global__ __launch_bounds__(64) void ll_decode_kernel(LlDecArgs A) {
-    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned t = SPREAD ? blockIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
+    if (SPREAD && threadIdx.x != 0) return;
     if (t >= A.n_ch) return;
     const LlChannelDev c = A.ch[t];
     int *out = A.scratch + c.out_off;
@@ -373,7 +378,8 @@ int launch_lossy_decode(const LossyDecArgs &A, unsigned max_frames, hipStream_t 
 }
 int launch_ll_decode(const LlDecArgs &A, hipStream_t s) {
     if (!A.n_ch) return 0;
-    hipLaunchKernelGGL(ll_decode_kernel, dim3((A.n_ch + 63) / 64), dim3(64), 0, s, A);
+    if (A.n_ch <= 8192) hipLaunchKernelGGL(ll_decode_kernel<1>, dim3(A.n_ch), dim3(64), 0, s, A);
+    else hipLaunchKernelGGL(ll_decode_kernel<0>, dim3((A.n_ch + 63) / 64), dim3(64), 0, s, A);
     FLO_LAUNCH_CHECK();
     return 0;
 }
