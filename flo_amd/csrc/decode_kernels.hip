@@ -269,6 +269,33 @@ __device__ __forceinline__ int rice_next(BitRd &r, uint32_t k) {   // one value 
     return (int)(u >> 1) ^ -(int)(u & 1u);
 }
 
+// reconstruct_lpc_int (decoder.rs:152-184): the first ORDER values are the residuals themselves, then
+// s[i] = ((sum_j coef[j] * s[i - 1 - j]) >> shift) + r[i] with i64 accumulation and a wrapping add
+template <int ORDER>
+__device__ __forceinline__ void lpc_decode(const LlChannelDev &c, const uint8_t *res, int *out) {
+    BitRd r;
+    r.init(res, c.len);
+    int hist[ORDER];   // hist[j] = s[i - 1 - j]
+#pragma unroll
+    for (int j = 0; j < ORDER; j++) hist[j] = 0;
+    const uint32_t sh = c.shift_bits & 63u;
+    const uint32_t n = c.samples;
+    for (uint32_t i = 0; i < n; i++) {
+        const int rv = rice_next(r, c.rice_k);
+        int v = rv;
+        if (i >= (uint32_t)ORDER) {
+            long long pred = 0;
+#pragma unroll
+            for (int j = 0; j < ORDER; j++) pred += (long long)c.coeffs[j] * (long long)hist[j];
+            v = (int)((unsigned)(int)(pred >> sh) + (unsigned)rv);
+        }
+        out[i] = v;
+#pragma unroll
+        for (int j = ORDER - 1; j > 0; j--) hist[j] = hist[j - 1];
+        hist[0] = v;
+    }
+}
+
 // SPREAD = 1: one channel wrapper per wavefront (lane 0 only). The walk is serial and data-dependent, so lanes of one
 // wave that decode different streams execute the union of their paths (measured: 380 instructions per sample with 20
 // lanes against ~150 alone); with few wrappers (a single file) a wave each is faster, with many the lanes are needed.
@@ -304,28 +331,21 @@ __global__ __launch_bounds__(64) void ll_decode_kernel(LlDecArgs A) {
         return;
     }
     if (has_coeffs) {
-        // reconstruct_lpc_int (decoder.rs:152-184): the first `order` values are the residuals themselves
-        const int order = c.n_coeffs;
-        BitRd r;
-        r.init(res, c.len);
-        int hist[12];
-#pragma unroll
-        for (int j = 0; j < 12; j++) hist[j] = 0;   // hist[j] = s[i - 1 - j]
-        const uint32_t sh = c.shift_bits & 63u;
-        for (uint32_t i = 0; i < n; i++) {
-            const int rv = rice_next(r, c.rice_k);
-            int v = rv;
-            if ((int)i >= order) {
-                long long pred = 0;
-#pragma unroll
-                for (int j = 0; j < 12; j++)
-                    if (j < order) pred += (long long)c.coeffs[j] * (long long)hist[j];
-                v = (int)((unsigned)(int)(pred >> sh) + (unsigned)rv);
-            }
-            out[i] = v;
-#pragma unroll
-            for (int j = 11; j > 0; j--) hist[j] = hist[j - 1];
-            hist[0] = v;
+        // reconstruct_lpc_int (decoder.rs:152-184), one instantiation per order so that the history shift and the
+        // multiply-adds are exactly `order` long
+        switch (c.n_coeffs) {
+            case 1: lpc_decode<1>(c, res, out); break;
+            case 2: lpc_decode<2>(c, res, out); break;
+            case 3: lpc_decode<3>(c, res, out); break;
+            case 4: lpc_decode<4>(c, res, out); break;
+            case 5: lpc_decode<5>(c, res, out); break;
+            case 6: lpc_decode<6>(c, res, out); break;
+            case 7: lpc_decode<7>(c, res, out); break;
+            case 8: lpc_decode<8>(c, res, out); break;
+            case 9: lpc_decode<9>(c, res, out); break;
+            case 10: lpc_decode<10>(c, res, out); break;
+            case 11: lpc_decode<11>(c, res, out); break;
+            default: lpc_decode<12>(c, res, out); break;
         }
         return;
     }
