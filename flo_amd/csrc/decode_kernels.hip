@@ -212,7 +212,14 @@ struct BitRd {
         cnt = 0;
     }
     __device__ __forceinline__ void refill() {
-        while (cnt <= 56 && pos < len) {
+        if (cnt <= 32 && pos + 4 <= len) {   // four bytes at once (any alignment), big-endian into the queue
+            uint32_t w;
+            __builtin_memcpy(&w, p + pos, 4);
+            buf |= (unsigned long long)__builtin_bswap32(w) << (32 - cnt);
+            pos += 4;
+            cnt += 32;
+        }
+        while (cnt <= 56 && pos < len && pos + 4 > len) {   // the last three bytes
             buf |= (unsigned long long)p[pos++] << (56 - cnt);
             cnt += 8;
         }
