@@ -161,7 +161,7 @@ __device__ __forceinline__ int lpc_residual(const int *__restrict__ s, unsigned 
 
 // Levinson-Durbin in f64 then fixed point (lpc.rs:225-276). No fused multiply-add anywhere: Rust never contracts.
 #pragma clang fp contract(off)
-__device__ bool levinson_fixed(const long long *autocorr, int order, int *coefs_out, int *shift_out) {
+__device__ bool levinson_fixed(const long long *autocorr, int order, int *coefs_out, int *shift_out, double *err_out) {
     if (autocorr[0] == 0) return false;
     double coeffs[kMaxOrder], nc[kMaxOrder];
     for (int i = 0; i < kMaxOrder; i++) coeffs[i] = 0.0;
@@ -210,6 +210,7 @@ __device__ bool levinson_fixed(const long long *autocorr, int order, int *coefs_
         coefs_out[i] = c;
     }
     *shift_out = shift;
+    *err_out = error;
     return true;
 }
 #pragma clang fp contract(fast)
@@ -295,6 +296,8 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
     __shared__ int s_valid[kNumCand];
     __shared__ int s_coef[8][kMaxOrder];
     __shared__ int s_shift[8];
+    __shared__ int s_kw0[8];      // first Rice parameter of the three-wide window tried during sweep 2
+    __shared__ int s_need3[8];    // the window missed: the candidate still needs sweep 3
     __shared__ unsigned long long s_bits[kNumCand];
 
     const unsigned int f = blockIdx.x / (unsigned int)A.nch, c = blockIdx.x % (unsigned int)A.nch;
@@ -399,9 +402,18 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
             s_valid[ci] = 0;
             if (try_lpc && ord <= max_order && n > (unsigned int)ord) {
                 int sh;
-                if (levinson_fixed(s_ac, ord, s_coef[ord - 5], &sh)) {
+                double err;
+                if (levinson_fixed(s_ac, ord, s_coef[ord - 5], &sh, &err)) {
                     s_shift[ord - 5] = sh;
                     s_valid[ci] = 1;
+                    // Guess of the Rice parameter from the predicted residual energy (mean |r| of a Laplacian is
+                    // sigma / sqrt 2): sweep 2 counts code lengths for the guess and its two neighbours, so that
+                    // the third sweep is only needed when the true parameter falls outside (never wrong, only slower).
+                    double mean = err > 0.0 ? sqrt(err / (double)n) * 0.70710678 : 0.0;
+                    unsigned int mi = mean < 4.0e9 ? (unsigned int)mean : 0xFFFFFFFFu;
+                    int kg = mi ? 32 - __clz((int)mi) : 0;
+                    kg = kg > 15 ? 15 : kg;
+                    s_kw0[ord - 5] = kg >= 14 ? 13 : (kg > 0 ? kg - 1 : 0);
                 }
             }
         }
@@ -424,8 +436,9 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
         unsigned long long fb[5];
         unsigned long long ls[8];
         unsigned int lm[8];
+        unsigned int lw[8][3];   // code-length sums for the window of Rice parameters (a thread sees < 2^23 / 256 samples)
         for (int o = 0; o < 5; o++) fb[o] = 0;
-        for (int o = 0; o < 8; o++) { ls[o] = 0; lm[o] = 0; }
+        for (int o = 0; o < 8; o++) { ls[o] = 0; lm[o] = 0; lw[o][0] = lw[o][1] = lw[o][2] = 0; }
         int kf[5];
         for (int o = 0; o < 5; o++) kf[o] = s_k[1 + o];
         for (unsigned int t0 = 0; t0 < n; t0 += tile) {
@@ -451,13 +464,18 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
                     int coef[kMaxOrder];
 #pragma unroll
                     for (int q = 0; q < kMaxOrder; q++) coef[q] = q < ord ? s_coef[oi][q] : 0;
-                    const int sh = s_shift[oi];
+                    const int sh = s_shift[oi], k0 = s_kw0[oi];
 #pragma unroll
                     for (int j = 0; j < kRun; j++)
                         if (i0 + j < n) {
-                            const unsigned int a = uabs(lpc_res(w, i0 + j, j, ord, coef, sh));
+                            const int rr = lpc_res(w, i0 + j, j, ord, coef, sh);
+                            const unsigned int a = uabs(rr);
                             ls[oi] += a;
                             lm[oi] = lm[oi] > a ? lm[oi] : a;
+                            const unsigned int u0 = zigzag(rr) >> k0;
+                            lw[oi][0] += u0 < 255u ? u0 : 255u;
+                            lw[oi][1] += (u0 >> 1) < 255u ? (u0 >> 1) : 255u;
+                            lw[oi][2] += (u0 >> 2) < 255u ? (u0 >> 2) : 255u;
                         }
                 }
             }
@@ -472,15 +490,28 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
                 if (!s_valid[ci]) continue;  // uniform across the block
                 unsigned long long t = block_sum(ls[ord - 5], red64);
                 unsigned int m = block_max(lm[ord - 5], red32);
+                unsigned long long w0 = block_sum((unsigned long long)lw[ord - 5][0], red64);
+                unsigned long long w1 = block_sum((unsigned long long)lw[ord - 5][1], red64);
+                unsigned long long w2 = block_sum((unsigned long long)lw[ord - 5][2], red64);
                 if (threadIdx.x == 0) {
-                    if (m > 1000000u) s_valid[ci] = 0;  // encoder.rs:269-272
-                    else s_k[ci] = rice_k(t, m, n);
+                    s_need3[ord - 5] = 0;
+                    if (m > 1000000u) {
+                        s_valid[ci] = 0;  // encoder.rs:269-272
+                    } else {
+                        const int k = rice_k(t, m, n), d = k - s_kw0[ord - 5];
+                        s_k[ci] = k;
+                        if (d >= 0 && d <= 2) s_bits[ci] = (d == 0 ? w0 : (d == 1 ? w1 : w2)) + (unsigned long long)n * (1 + k);
+                        else s_need3[ord - 5] = 1;
+                    }
                 }
             }
     }
     __syncthreads();
-    // ---- sweep 3: code lengths of the surviving LPC candidates
-    if (try_lpc) {
+    // ---- sweep 3: code lengths of the surviving LPC candidates whose Rice parameter fell outside the window
+    bool any3 = false;
+    if (try_lpc)
+        for (int ord = 5; ord <= max_order; ord++) any3 |= s_valid[6 + ord - 5] && s_need3[ord - 5];
+    if (any3) {
         unsigned long long lb[8];
         for (int o = 0; o < 8; o++) lb[o] = 0;
         for (unsigned int t0 = 0; t0 < n; t0 += tile) {
@@ -491,7 +522,7 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
 #pragma unroll
             for (int oi = 0; oi < 8; oi++) {
                 const int ord = 5 + oi;
-                if (ord > max_order || !s_valid[6 + oi]) continue;
+                if (ord > max_order || !s_valid[6 + oi] || !s_need3[oi]) continue;
                 int coef[kMaxOrder];
 #pragma unroll
                 for (int q = 0; q < kMaxOrder; q++) coef[q] = q < ord ? s_coef[oi][q] : 0;
@@ -506,7 +537,7 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
         }
         for (int ord = 5; ord <= max_order; ord++) {
             const int ci = 6 + ord - 5;
-            if (!s_valid[ci]) continue;
+            if (!s_valid[ci] || !s_need3[ord - 5]) continue;
             unsigned long long t = block_sum(lb[ord - 5], red64);
             if (threadIdx.x == 0) s_bits[ci] = t + (unsigned long long)n * (1 + s_k[ci]);
         }
