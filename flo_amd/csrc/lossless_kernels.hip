@@ -31,6 +31,7 @@ namespace flo {
 constexpr int kLLThreads = 256;
 constexpr int kMaxOrder = 12;
 constexpr int kNumCand = 1 + 5 + 8;  // raw, fixed 0..4, lpc 5..12
+constexpr unsigned int kStageWords = 4096;   // 16 KiB: a tile of 4096 samples at up to 32 bits per sample
 
 struct LLFrame {              // one 1-second frame of one clip (host-planned)
     unsigned long long pcm_off;   // float offset of the frame slice from the PCM base
@@ -659,6 +660,7 @@ struct BitSink {
 
 __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
     __shared__ unsigned long long sc[kLLThreads];
+    __shared__ unsigned int stage[kStageWords];   // one tile's bits (big-endian words), composed here, stored whole
     const unsigned int f = blockIdx.x / (unsigned int)A.nch, c = blockIdx.x % (unsigned int)A.nch;
     if (f >= A.n_frames) return;
     const LLFrame fr = A.frames[f];
@@ -762,10 +764,71 @@ __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
             sc[threadIdx.x] += t;
             __syncthreads();
         }
-        const unsigned long long start_bit = tile_bit + sc[threadIdx.x] - bits;
-        tile_bit += sc[kLLThreads - 1];
-        if (i0 < i1) {
-            const unsigned long long abs_bit = bit0 + start_bit;
+        const unsigned long long tile_total = sc[kLLThreads - 1];
+        const unsigned long long rel_bit = sc[threadIdx.x] - bits;            // inside the tile
+        const unsigned long long tile_abs = bit0 + tile_bit;                   // absolute bit position of the tile
+        tile_bit += tile_total;
+        // The tile's bits are composed in LDS and leave as whole words: only the first and the last word of a tile can
+        // be shared with a neighbour and need a global atomic OR (it was two atomics per THREAD before, and the L2's
+        // atomic rate was what bounded the kernel). A tile too long for the staging buffer (very noisy material at a
+        // small Rice parameter) keeps the direct path.
+        const unsigned int lead = (unsigned int)(tile_abs & 31ull);            // the tile starts inside this word
+        const unsigned long long span = lead + tile_total;
+        const bool staged = span <= 32ull * kStageWords;
+        if (staged) {
+            const unsigned int nw = (unsigned int)((span + 31ull) >> 5);
+            for (unsigned int i = threadIdx.x; i < nw; i += kLLThreads) stage[i] = 0u;
+            __syncthreads();
+            if (i0 < i1) {
+                unsigned long long pos = lead + rel_bit;
+                unsigned int word = (unsigned int)(pos >> 5), acc = 0;
+                int fill = (int)(pos & 31ull);
+                bool first = true;
+                auto flush = [&](bool shared) {
+                    if (shared) { if (acc) atomicOr(&stage[word], acc); }
+                    else stage[word] = acc;
+                    word++;
+                    acc = 0;
+                    fill = 0;
+                    first = false;
+                };
+                auto put = [&](unsigned int value, int nbits) {   // nbits <= 32, value < 2^nbits, MSB-first
+                    while (nbits > 0) {
+                        const int room = 32 - fill;
+                        const int take = nbits < room ? nbits : room;
+                        const unsigned int part = (take == 32) ? value : ((value >> (nbits - take)) & ((1u << take) - 1u));
+                        acc |= (take == 32) ? part : (part << (room - take));
+                        fill += take;
+                        nbits -= take;
+                        if (fill == 32) flush(first);
+                    }
+                };
+#pragma unroll
+                for (unsigned int j = 0; j < kPer; j++) {
+                    if (i0 + j < i1) {
+                        unsigned int q = u[j] >> k;
+                        q = q < 255u ? q : 255u;
+                        unsigned int ones = q;
+                        while (ones >= 32) {
+                            put(0xFFFFFFFFu, 32);
+                            ones -= 32;
+                        }
+                        if (ones + 1 <= 32) put(ones ? (((1u << ones) - 1u) << 1) : 0u, (int)ones + 1);
+                        if (k) put(u[j] & ((1u << k) - 1u), k);
+                    }
+                }
+                if (fill > 0) flush(true);
+            }
+            __syncthreads();
+            unsigned int *gw = reinterpret_cast<unsigned int *>(base4) + (tile_abs >> 5);
+            for (unsigned int i = threadIdx.x; i < nw; i += kLLThreads) {
+                const unsigned int v = __builtin_bswap32(stage[i]);     // words are big-endian bit containers
+                if (i == 0 || i + 1 == nw) { if (v) atomicOr(gw + i, v); }
+                else gw[i] = v;
+            }
+            // the next tile zeroes `stage` only after its own scan, i.e. behind two barriers: no extra one needed here
+        } else if (i0 < i1) {
+            const unsigned long long abs_bit = tile_abs + rel_bit;
             BitSink bs;
             bs.out = base4;
             bs.word = abs_bit >> 5;
