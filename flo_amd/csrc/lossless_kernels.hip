@@ -288,6 +288,8 @@ struct CandStats {
     unsigned int max_abs;
 };
 
+// MAXO = level_to_order(level) (encoder.rs:289-302): a compile-time bound for every lag / order loop
+template <int MAXO>
 __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
     __shared__ unsigned long long red64[kLLThreads / 64];
     __shared__ long long redi64[kLLThreads / 64];
@@ -315,8 +317,9 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
     }
     const unsigned int n = out->n;
     const int *s = A.planes + fr.plane_off + (size_t)c * fr.plane_stride;
-    const int max_order = A.max_order;
-    const int fixed_max = max_order < 4 ? max_order : 4;
+    constexpr int max_order = MAXO;
+    constexpr int kLpcOrders = MAXO > 4 ? MAXO - 4 : 0;   // LPC candidates: orders 5..MAXO
+    constexpr int fixed_max = max_order < 4 ? max_order : 4;
     const bool try_lpc = A.level >= 3 && max_order > 4;
     // The plane is walked in tiles of 256 threads x 16 consecutive samples. A thread keeps its 16 samples and the 12
     // before them in registers (kWin), so every predictor tap of every candidate is a register operand: the plane is
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
 #ifndef FLO_LL_RUN
 #define FLO_LL_RUN 16
 #endif
-    constexpr int kRun = FLO_LL_RUN, kHist = kMaxOrder, kWin = kRun + kHist;
+    constexpr int kRun = FLO_LL_RUN, kHist = MAXO > 4 ? MAXO : 4, kWin = kRun + kHist;
     const unsigned int tile = kLLThreads * kRun;
     auto load_window = [&](unsigned int i0, int (&w)[kWin]) {
 #pragma unroll
@@ -351,10 +354,10 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
 
     // ---- sweep 1: autocorrelation lags 0..max_order (lpc.rs:213-221) and fixed-predictor statistics
     {
-        long long ac[kMaxOrder + 1];
+        long long ac[MAXO + 1];
         unsigned long long fs[5];
         unsigned int fm[5];
-        for (int l = 0; l <= kMaxOrder; l++) ac[l] = 0;
+        for (int l = 0; l <= MAXO; l++) ac[l] = 0;
         for (int o = 0; o < 5; o++) { fs[o] = 0; fm[o] = 0; }
         for (unsigned int t0 = 0; t0 < n; t0 += tile) {
             const unsigned int i0 = t0 + threadIdx.x * kRun;
@@ -368,8 +371,8 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
                 if (try_lpc) {
                     const long long si = w[kHist + j];
 #pragma unroll
-                    for (int l = 0; l <= kMaxOrder; l++)
-                        if (l <= max_order && (unsigned int)l <= i) ac[l] += si * (long long)w[kHist + j - l];
+                    for (int l = 0; l <= MAXO; l++)
+                        if ((unsigned int)l <= i) ac[l] += si * (long long)w[kHist + j - l];
                 }
 #pragma unroll
                 for (int o = 0; o < 5; o++)
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
         if (i < (unsigned int)ord) return w[kHist + j];
         long long pred = 0;
 #pragma unroll
-        for (int q = 0; q < kMaxOrder; q++)
+        for (int q = 0; q < MAXO; q++)
             if (q < ord) pred += (long long)coef[q] * (long long)w[kHist + j - 1 - q];
         pred >>= shift;
         return (int)((unsigned int)w[kHist + j] - (unsigned int)(int)pred);
@@ -435,11 +438,12 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
     // ---- sweep 2: code lengths of the fixed candidates, statistics of the LPC candidates
     {
         unsigned long long fb[5];
-        unsigned long long ls[8];
-        unsigned int lm[8];
-        unsigned int lw[8][3];   // code-length sums for the window of Rice parameters (a thread sees < 2^23 / 256 samples)
+        constexpr int NL = kLpcOrders > 0 ? kLpcOrders : 1;
+        unsigned long long ls[NL];
+        unsigned int lm[NL];
+        unsigned int lw[NL][3];   // code-length sums for the window of Rice parameters (a thread sees < 2^23 / 256 samples)
         for (int o = 0; o < 5; o++) fb[o] = 0;
-        for (int o = 0; o < 8; o++) { ls[o] = 0; lm[o] = 0; lw[o][0] = lw[o][1] = lw[o][2] = 0; }
+        for (int o = 0; o < NL; o++) { ls[o] = 0; lm[o] = 0; lw[o][0] = lw[o][1] = lw[o][2] = 0; }
         int kf[5];
         for (int o = 0; o < 5; o++) kf[o] = s_k[1 + o];
         for (unsigned int t0 = 0; t0 < n; t0 += tile) {
@@ -459,12 +463,12 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
                 }
             if (try_lpc) {
 #pragma unroll
-                for (int oi = 0; oi < 8; oi++) {
+                for (int oi = 0; oi < kLpcOrders; oi++) {
                     const int ord = 5 + oi;
-                    if (ord > max_order || !s_valid[6 + oi]) continue;   // uniform across the block
-                    int coef[kMaxOrder];
+                    if (!s_valid[6 + oi]) continue;   // uniform across the block
+                    int coef[NL + 4];
 #pragma unroll
-                    for (int q = 0; q < kMaxOrder; q++) coef[q] = q < ord ? s_coef[oi][q] : 0;
+                    for (int q = 0; q < NL + 4; q++) coef[q] = q < ord ? s_coef[oi][q] : 0;
                     const int sh = s_shift[oi], k0 = s_kw0[oi];
 #pragma unroll
                     for (int j = 0; j < kRun; j++)
@@ -513,20 +517,21 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
     if (try_lpc)
         for (int ord = 5; ord <= max_order; ord++) any3 |= s_valid[6 + ord - 5] && s_need3[ord - 5];
     if (any3) {
-        unsigned long long lb[8];
-        for (int o = 0; o < 8; o++) lb[o] = 0;
+        constexpr int NL = kLpcOrders > 0 ? kLpcOrders : 1;
+        unsigned long long lb[NL];
+        for (int o = 0; o < NL; o++) lb[o] = 0;
         for (unsigned int t0 = 0; t0 < n; t0 += tile) {
             const unsigned int i0 = t0 + threadIdx.x * kRun;
             if (i0 >= n) continue;
             int w[kWin];
             load_window(i0, w);
 #pragma unroll
-            for (int oi = 0; oi < 8; oi++) {
+            for (int oi = 0; oi < kLpcOrders; oi++) {
                 const int ord = 5 + oi;
-                if (ord > max_order || !s_valid[6 + oi] || !s_need3[oi]) continue;
-                int coef[kMaxOrder];
+                if (!s_valid[6 + oi] || !s_need3[oi]) continue;
+                int coef[NL + 4];
 #pragma unroll
-                for (int q = 0; q < kMaxOrder; q++) coef[q] = q < ord ? s_coef[oi][q] : 0;
+                for (int q = 0; q < NL + 4; q++) coef[q] = q < ord ? s_coef[oi][q] : 0;
                 const int sh = s_shift[oi], kk = s_k[6 + oi];
 #pragma unroll
                 for (int j = 0; j < kRun; j++)
@@ -1015,7 +1020,15 @@ int lossless_encode_launch(LosslessPlan *p, hipStream_t s, int profile, std::str
     A.frame_size = p->d_fsize;
     if (nf) {
         hipLaunchKernelGGL(ll_prepare_kernel, dim3(nf), dim3(kLLThreads), 0, s, A);
-        hipLaunchKernelGGL(ll_analyze_kernel, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A);
+        switch (p->max_order) {   // encoder.rs:289-302 yields exactly these orders
+            case 0: hipLaunchKernelGGL(ll_analyze_kernel<0>, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A); break;
+            case 2: hipLaunchKernelGGL(ll_analyze_kernel<2>, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A); break;
+            case 4: hipLaunchKernelGGL(ll_analyze_kernel<4>, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A); break;
+            case 6: hipLaunchKernelGGL(ll_analyze_kernel<6>, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A); break;
+            case 8: hipLaunchKernelGGL(ll_analyze_kernel<8>, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A); break;
+            case 10: hipLaunchKernelGGL(ll_analyze_kernel<10>, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A); break;
+            default: hipLaunchKernelGGL(ll_analyze_kernel<12>, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A); break;
+        }
         hipLaunchKernelGGL(ll_layout_kernel, dim3((A.n_clips + 63) / 64), dim3(64), 0, s, A);
         hipLaunchKernelGGL(ll_pack_kernel, dim3(nf * p->ch), dim3(kLLThreads), 0, s, A);
     }
