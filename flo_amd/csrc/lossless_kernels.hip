@@ -747,10 +747,22 @@ __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
                     } else if (i < (unsigned int)ch.order) {   // LPC warm-up copies the samples (lpc.rs:279-298)
                         r = x0;
                     } else {
+                        // exactly `order` multiply-adds: the order is uniform over the workgroup, so the switch is a
+                        // scalar branch and each arm a straight line
                         long long pred = 0;
+                        switch (ch.order) {
+#define FLO_TAPS(N)                                                                                   \
+    case N:                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < N; q++) pred += (long long)ch.coefs[q] * (long long)w[kMaxOrder + j - 1 - q]; \
+        break;
+                            FLO_TAPS(5) FLO_TAPS(6) FLO_TAPS(7) FLO_TAPS(8) FLO_TAPS(9) FLO_TAPS(10) FLO_TAPS(11)
+                            default:
 #pragma unroll
-                        for (int q = 0; q < kMaxOrder; q++)
-                            if (q < ch.order) pred += (long long)ch.coefs[q] * (long long)w[kMaxOrder + j - 1 - q];
+                                for (int q = 0; q < kMaxOrder; q++)
+                                    if (q < ch.order) pred += (long long)ch.coefs[q] * (long long)w[kMaxOrder + j - 1 - q];
+                                break;
+#undef FLO_TAPS
+                        }
                         pred >>= ch.shift;
                         r = (int)((unsigned int)x0 - (unsigned int)(int)pred);
                     }
