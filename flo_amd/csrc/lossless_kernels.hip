@@ -337,19 +337,35 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
             w[j] = (idx >= 0 && idx < (long long)n) ? s[idx] : 0;
         }
     };
-    // residual of the fixed predictor `o` at position i = i0 + j (lpc.rs:301-359; positions below the order use order i)
-    auto fixed_res = [&](const int (&w)[kWin], unsigned int i, int j, int o) {
-        const int oo = o < (int)i ? o : (int)i;
-        const long long x0 = w[kHist + j], x1 = w[kHist + j - 1], x2 = w[kHist + j - 2], x3 = w[kHist + j - 3], x4 = w[kHist + j - 4];
-        long long v;
-        switch (oo) {
-            case 0: v = x0; break;
-            case 1: v = x0 - x1; break;
-            case 2: v = x0 - 2ll * x1 + x2; break;
-            case 3: v = x0 - 3ll * x1 + 3ll * x2 - x3; break;
-            default: v = x0 - 4ll * x1 + 6ll * x2 - 4ll * x3 + x4; break;
+    // All fixed-predictor residuals of a run by repeated differencing: order o is the difference of two order o - 1
+    // residuals (in wrapping 32-bit arithmetic this equals the binomial form truncated from i64), 4.4 subtractions
+    // per sample for the five orders together. D[o][j] is the order-o residual of sample i0 + j computed with zeros in
+    // front of the plane; positions below the order take the lower order (lpc.rs:301-359), which only ever concerns
+    // the first four samples of the plane.
+    auto fixed_all = [&](const int (&w)[kWin], unsigned int i0, unsigned int (&D)[5][kRun]) {
+        unsigned int d1[kRun + 3], d2[kRun + 2], d3[kRun + 1];
+#pragma unroll
+        for (int j = 0; j < kRun + 3; j++) d1[j] = (unsigned int)w[kHist + j - 3] - (unsigned int)w[kHist + j - 4];
+#pragma unroll
+        for (int j = 0; j < kRun + 2; j++) d2[j] = d1[j + 1] - d1[j];
+#pragma unroll
+        for (int j = 0; j < kRun + 1; j++) d3[j] = d2[j + 1] - d2[j];
+#pragma unroll
+        for (int j = 0; j < kRun; j++) {
+            D[0][j] = (unsigned int)w[kHist + j];
+            D[1][j] = d1[j + 3];
+            D[2][j] = d2[j + 2];
+            D[3][j] = d3[j + 1];
+            D[4][j] = d3[j + 1] - d3[j];
         }
-        return (int)(unsigned int)(unsigned long long)v;
+        if (i0 == 0) {   // warm-up of the plane's first samples: position i uses order min(o, i)
+            static_assert(kRun >= 4, "the warm-up fix-up touches the first four samples of a run");
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int o = 1; o < 5; o++)
+                    if (o > j) D[o][j] = D[j][j];
+        }
     };
 
     // ---- sweep 1: autocorrelation lags 0..max_order (lpc.rs:213-221) and fixed-predictor statistics
@@ -364,6 +380,8 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
             if (i0 >= n) continue;
             int w[kWin];
             load_window(i0, w);
+            unsigned int D[5][kRun];
+            fixed_all(w, i0, D);
 #pragma unroll
             for (int j = 0; j < kRun; j++) {
                 const unsigned int i = i0 + j;
@@ -377,7 +395,7 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
 #pragma unroll
                 for (int o = 0; o < 5; o++)
                     if (o <= fixed_max) {
-                        const unsigned int a = uabs(fixed_res(w, i, j, o));
+                        const unsigned int a = uabs((int)D[o][j]);
                         fs[o] += a;
                         fm[o] = fm[o] > a ? fm[o] : a;
                     }
@@ -451,16 +469,20 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
             if (i0 >= n) continue;
             int w[kWin];
             load_window(i0, w);
+            {
+                unsigned int D[5][kRun];
+                fixed_all(w, i0, D);
 #pragma unroll
-            for (int o = 0; o < 5; o++)
-                if (o <= fixed_max) {
+                for (int o = 0; o < 5; o++)
+                    if (o <= fixed_max) {
 #pragma unroll
-                    for (int j = 0; j < kRun; j++)
-                        if (i0 + j < n) {
-                            unsigned int q = zigzag(fixed_res(w, i0 + j, j, o)) >> kf[o];
-                            fb[o] += q < 255u ? q : 255u;
-                        }
-                }
+                        for (int j = 0; j < kRun; j++)
+                            if (i0 + j < n) {
+                                unsigned int q = zigzag((int)D[o][j]) >> kf[o];
+                                fb[o] += q < 255u ? q : 255u;
+                            }
+                    }
+            }
             if (try_lpc) {
 #pragma unroll
                 for (int oi = 0; oi < kLpcOrders; oi++) {
@@ -663,6 +685,51 @@ struct BitSink {
     }
 };
 
+// Zigzag codes u[j] of the 16 samples of a run and the sum of their Rice code lengths. ORD = 0: fixed predictor of
+// order ch.order (lpc.rs:301-359; positions below the order use order i); ORD >= 5: LPC of exactly ORD taps
+// (lpc.rs:279-298: the first ORD samples of the plane are copied, then i64 dot product, arithmetic shift, wrapping
+// subtraction). w holds the 12 samples before the run and the run itself.
+template <int ORD>
+__device__ __forceinline__ unsigned long long run_codes(const LLChan &ch, const int (&w)[16 + kMaxOrder], unsigned int i0,
+                                                        unsigned int i1, int k, unsigned int (&u)[16]) {
+    unsigned long long bits = 0;
+#pragma unroll
+    for (unsigned int j = 0; j < 16; j++) {
+        const unsigned int i = i0 + j;
+        u[j] = 0;
+        if (i < i1) {
+            const int x0 = w[kMaxOrder + j];
+            int r;
+            if (ORD == 0) {
+                const int oo = ch.order < (int)i ? ch.order : (int)i;
+                const long long x1 = w[kMaxOrder + j - 1], x2 = w[kMaxOrder + j - 2], x3 = w[kMaxOrder + j - 3],
+                                x4 = w[kMaxOrder + j - 4];
+                long long v;
+                switch (oo) {
+                    case 0: v = x0; break;
+                    case 1: v = (long long)x0 - x1; break;
+                    case 2: v = (long long)x0 - 2ll * x1 + x2; break;
+                    case 3: v = (long long)x0 - 3ll * x1 + 3ll * x2 - x3; break;
+                    default: v = (long long)x0 - 4ll * x1 + 6ll * x2 - 4ll * x3 + x4; break;
+                }
+                r = (int)(unsigned int)(unsigned long long)v;
+            } else if (i < (unsigned int)ORD) {
+                r = x0;
+            } else {
+                long long pred = 0;
+#pragma unroll
+                for (int q = 0; q < ORD; q++) pred += (long long)ch.coefs[q] * (long long)w[kMaxOrder + j - 1 - q];
+                pred >>= ch.shift;
+                r = (int)((unsigned int)x0 - (unsigned int)(int)pred);
+            }
+            u[j] = zigzag(r);
+            unsigned int q = u[j] >> k;
+            bits += (q < 255u ? q : 255u) + 1u + (unsigned int)k;
+        }
+    }
+    return bits;
+}
+
 __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
     __shared__ unsigned long long sc[kLLThreads];
     __shared__ unsigned int stage[kStageWords];   // one tile's bits (big-endian words), composed here, stored whole
@@ -685,7 +752,8 @@ __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
             unsigned long long p = pos + 4;
             const int ncoef = ch.kind == 2 ? ch.order : 0;
             or_bytes(out, p++, (unsigned int)ncoef, 1);
-            for (int j = 0; j < ncoef; j++, p += 4) or_bytes(out, p, (unsigned int)ch.coefs[j], 4);
+            // indexed through the global record: a run-time index into the register copy would push all of it to scratch
+            for (int j = 0; j < ncoef; j++, p += 4) or_bytes(out, p, (unsigned int)A.chans[fr.first_chan + c].coefs[j], 4);
             const unsigned int shift_bits = ch.kind == 1 ? 128u + (unsigned int)ch.order : (ch.kind == 2 ? (unsigned int)ch.shift : 0u);
             or_bytes(out, p++, shift_bits, 1);
             or_bytes(out, p++, ch.kind == 0 ? 2u : 0u, 1);  // ResidualEncoding::Raw = 2, Rice = 0
@@ -724,51 +792,20 @@ __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
                 const long long idx = (long long)i0 - kMaxOrder + j;
                 w[j] = (idx >= 0 && idx < (long long)n) ? s[idx] : 0;
             }
-#pragma unroll
-            for (unsigned int j = 0; j < kPer; j++) {
-                const unsigned int i = i0 + j;
-                u[j] = 0;
-                if (i < i1) {
-                    const int x0 = w[kMaxOrder + j];
-                    int r;
-                    if (ch.kind == 1) {   // fixed predictor (lpc.rs:301-359); positions below the order use order i
-                        const int oo = ch.order < (int)i ? ch.order : (int)i;
-                        const long long x1 = w[kMaxOrder + j - 1], x2 = w[kMaxOrder + j - 2], x3 = w[kMaxOrder + j - 3],
-                                        x4 = w[kMaxOrder + j - 4];
-                        long long v;
-                        switch (oo) {
-                            case 0: v = x0; break;
-                            case 1: v = (long long)x0 - x1; break;
-                            case 2: v = (long long)x0 - 2ll * x1 + x2; break;
-                            case 3: v = (long long)x0 - 3ll * x1 + 3ll * x2 - x3; break;
-                            default: v = (long long)x0 - 4ll * x1 + 6ll * x2 - 4ll * x3 + x4; break;
-                        }
-                        r = (int)(unsigned int)(unsigned long long)v;
-                    } else if (i < (unsigned int)ch.order) {   // LPC warm-up copies the samples (lpc.rs:279-298)
-                        r = x0;
-                    } else {
-                        // exactly `order` multiply-adds: the order is uniform over the workgroup, so the switch is a
-                        // scalar branch and each arm a straight line
-                        long long pred = 0;
-                        switch (ch.order) {
-#define FLO_TAPS(N)                                                                                   \
-    case N:                                                                                           \
-        _Pragma("unroll") for (int q = 0; q < N; q++) pred += (long long)ch.coefs[q] * (long long)w[kMaxOrder + j - 1 - q]; \
-        break;
-                            FLO_TAPS(5) FLO_TAPS(6) FLO_TAPS(7) FLO_TAPS(8) FLO_TAPS(9) FLO_TAPS(10) FLO_TAPS(11)
-                            default:
-#pragma unroll
-                                for (int q = 0; q < kMaxOrder; q++)
-                                    if (q < ch.order) pred += (long long)ch.coefs[q] * (long long)w[kMaxOrder + j - 1 - q];
-                                break;
-#undef FLO_TAPS
-                        }
-                        pred >>= ch.shift;
-                        r = (int)((unsigned int)x0 - (unsigned int)(int)pred);
-                    }
-                    u[j] = zigzag(r);
-                    unsigned int q = u[j] >> k;
-                    bits += (q < 255u ? q : 255u) + 1u + (unsigned int)k;
+            // residuals of the run: one straight-line instantiation per predictor (the choice is uniform over the
+            // workgroup), so every tap and every window index is a compile-time constant
+            if (ch.kind == 1) {
+                bits = run_codes<0>(ch, w, i0, i1, k, u);
+            } else {
+                switch (ch.order) {
+                    case 5: bits = run_codes<5>(ch, w, i0, i1, k, u); break;
+                    case 6: bits = run_codes<6>(ch, w, i0, i1, k, u); break;
+                    case 7: bits = run_codes<7>(ch, w, i0, i1, k, u); break;
+                    case 8: bits = run_codes<8>(ch, w, i0, i1, k, u); break;
+                    case 9: bits = run_codes<9>(ch, w, i0, i1, k, u); break;
+                    case 10: bits = run_codes<10>(ch, w, i0, i1, k, u); break;
+                    case 11: bits = run_codes<11>(ch, w, i0, i1, k, u); break;
+                    default: bits = run_codes<12>(ch, w, i0, i1, k, u); break;
                 }
             }
         }
