@@ -169,7 +169,8 @@ def main():
         "realtime_factor": round(value * 1e6 / (sr * ch), 1),
         "config": {
             "workload": f"{args.clips_per_gpu} x {args.clip_seconds:g} s 44.1 kHz stereo clips per GPU, lossy quality=high "
-                        f"(0.55): per-GPU shard of BASELINE configs[3] (10 000 clips / 8 GPUs)",
+                        f"(0.55): per-GPU shard of BASELINE configs[3] (10 000 clips / 8 GPUs), the config the metric's "
+                        f"1/2/4/8-GPU scaling is quoted on; configs[1] (one 3-min clip) is timed under single_clip_180s",
             "clips_per_gpu": args.clips_per_gpu, "clip_seconds": args.clip_seconds, "quality": args.quality,
             "kernel_form": {"lossy_chain3": "chain, three waves per stereo clip", "lossy_chain": "chain, one wave per channel", "lossy_frames": "frame-parallel"}[kname],
             "compressed_bytes_per_gpu": data_bytes,
