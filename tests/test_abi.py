@@ -56,3 +56,16 @@ def test_quality_preset_mirror():
         assert int(Q(i)) == i and Q.from_f32(Q(i).as_f32()) == Q(i)
     assert Q.from_bitrate(128, 44100, 2) == Q.Medium and Q.from_bitrate(320, 44100, 2) == Q.VeryHigh
     assert Q.from_bitrate(48, 44100, 2) == Q.Low and Q.from_bitrate(400, 44100, 2) == Q.Transparent
+
+
+def test_public_headers_compile_as_plain_c99(tmp_path):
+    # the boundary is a C ABI: the headers must be usable from C (and from the C subset a Rust bindgen run sees)
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include "flo_hip.h"\n#include "flo_synth.h"\nint main(void) { return FLO_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           "-fsyntax-only", str(src)])
