@@ -6,10 +6,12 @@
 
 A "step" is one pass of the encode hot path over the rank's batch of clips with the PCM already resident in HBM
 and the bitstreams left in HBM; for N > 1 the step ends with the RCCL gather of the packed bitstreams to rank 0.
-Workload (config.workload): every rank holds 1250 synthetic 10-second stereo clips — BASELINE.json's
-"10 000-clip corpus sharded across 8 GPUs" at its per-GPU share, the same at every N (weak scaling). The
-single 3-minute clip of configs[1] is timed in the same run and reported under "single_clip_180s": it is 63 MB
-of PCM, lives in the Infinity Cache and lasts tens of microseconds, so it cannot carry an HBM-roofline claim.
+Workload (config.workload): BASELINE.json configs[3], the 10 000-clip corpus of synthetic 10-second stereo clips
+(35 GB of f32 PCM, resident in HBM), whole on every GPU — the configuration the metric is quoted on; it fits one
+MI355X. The same per-GPU work at every N (weak scaling: N GPUs encode N corpora). At N = 1 the run also times the
+1250-clip per-GPU shard of the 8-way split ("shard_1250": one launch that fills the chip exactly once) and the single
+3-minute clip of configs[1] ("single_clip_180s": 63 MB of PCM, lives in the Infinity Cache and lasts a fraction of a
+millisecond, so it cannot carry an HBM-roofline claim).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -45,22 +47,39 @@ def host_cores():
     return n
 
 
-def hbm_traffic(kname, args):
+PROFILE_SUMMARY = "profiles/r02_profile_summary.json"
+
+
+def kernel_source_sha():
+    """Hash of the sources the lossy kernels are compiled from. profiles/summarize.py stores it in the summary it
+    writes; a summary measured on other kernel sources is stale and its counters are not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("lossy_kernels.hip", "lossy_device.hpp", "lossy_kernels.hpp"):
+        with open(os.path.join(ROOT, "flo_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def hbm_traffic(kname, clips, seconds):
     """HBM bytes per launch of the dominant kernel from the PMC passes of profiles/collect.sh (rocprofv3 cannot run
-    inside this process; the summary is of this same command and workload). None when there is no summary for the
-    kernel form and workload that just ran."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_profile_summary.json")
-    if args.clips_per_gpu != 1250 or args.clip_seconds != 10.0 or not os.path.exists(path):
-        return None, None
+    inside this process). Reported only when the committed summary was measured on THESE kernel sources and on this
+    workload; otherwise None (the counters would describe some other kernel)."""
+    path = os.path.join(ROOT, PROFILE_SUMMARY)
     try:
         with open(path) as fh:
-            ks = json.load(fh)["kernels"]
+            doc = json.load(fh)
+        if doc.get("kernel_source_sha") != kernel_source_sha():
+            return None, f"{PROFILE_SUMMARY} was measured on other kernel sources (stale): not reported"
+        if doc.get("clips_per_gpu") != clips or doc.get("clip_seconds") != seconds:
+            return None, f"{PROFILE_SUMMARY} holds another workload: not reported"
+        for name, e in doc["kernels"].items():
+            if ("::" + kname + "_kernel") in name and "hbm_read_bytes_per_launch" in e and "hbm_write_bytes_per_launch" in e:
+                return (int(e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]),
+                        f"{PROFILE_SUMMARY} (kernel sources {doc['kernel_source_sha']}): rocprofv3 --pmc FETCH_SIZE (x2, gfx950) "
+                        f"and --pmc WRITE_SIZE, separate passes of this command")
     except (OSError, ValueError, KeyError):
-        return None, None
-    for name, e in ks.items():
-        if ("::" + kname + "_kernel") in name and "hbm_read_bytes_per_launch" in e and "hbm_write_bytes_per_launch" in e:
-            return (int(e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]),
-                    "profiles/r01_profile_summary.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE, separate passes")
+        pass
     return None, None
 
 
@@ -69,13 +88,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--clips-per-gpu", type=int, default=1250)
+    ap.add_argument("--clips-per-gpu", type=int, default=10000)
     ap.add_argument("--clip-seconds", type=float, default=10.0)
     ap.add_argument("--quality", type=float, default=0.55)
     ap.add_argument("--path", type=int, default=0, help="0 auto, 1 two-wave chain kernel, 2 frame-parallel kernels, 3 three-wave chain kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-clip", action="store_true")
     ap.add_argument("--no-lossless", action="store_true")
+    ap.add_argument("--no-shard", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=200)
     args = ap.parse_args()
 
@@ -169,8 +189,9 @@ def main():
         "realtime_factor": round(value * 1e6 / (sr * ch), 1),
         "config": {
             "workload": f"{args.clips_per_gpu} x {args.clip_seconds:g} s 44.1 kHz stereo clips per GPU, lossy quality=high "
-                        f"(0.55): per-GPU shard of BASELINE configs[3] (10 000 clips / 8 GPUs), the config the metric's "
-                        f"1/2/4/8-GPU scaling is quoted on; configs[1] (one 3-min clip) is timed under single_clip_180s",
+                        f"(0.55)" + (": BASELINE configs[3], the 10 000-clip corpus, whole on each GPU (35 GB of PCM resident in "
+                                     "HBM); its 1250-clip shard is timed under shard_1250, configs[1] (one 3-min clip) under "
+                                     "single_clip_180s" if args.clips_per_gpu == 10000 and args.clip_seconds == 10.0 else ""),
             "clips_per_gpu": args.clips_per_gpu, "clip_seconds": args.clip_seconds, "quality": args.quality,
             "kernel_form": {"lossy_chain3": "chain, three waves per stereo clip", "lossy_chain": "chain, one wave per channel", "lossy_frames": "frame-parallel"}[kname],
             "compressed_bytes_per_gpu": data_bytes,
@@ -178,7 +199,7 @@ def main():
     }
     if k_n:
         per_launch_s = k_ms / k_n / 1e3
-        traffic, traffic_src = hbm_traffic(kname, args)
+        traffic, traffic_src = hbm_traffic(kname, args.clips_per_gpu, args.clip_seconds)
         achieved = ALG_BYTES_PER_SAMPLE * samples_per_step_rank / per_launch_s / 1e9
         out["roofline"] = {
             "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -186,6 +207,32 @@ def main():
             "traffic_source": traffic_src,
             "kernel_ms": round(k_ms / k_n, 4), "algorithmic_bytes_per_sample": round(ALG_BYTES_PER_SAMPLE, 4),
         }
+
+    if not args.no_shard and world == 1 and args.clips_per_gpu != 1250:
+        # the per-GPU share of the 8-way split of configs[3]: 1250 clips = 250 workgroups of five, one launch that
+        # fills the 256 CUs exactly once (what round 1 reported as the headline)
+        bs = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [n_il] * 1250, sr, ch, args.quality)
+        bs.fill_synthetic(seed=0xF10A0D10, clip_id0=0)
+        for _ in range(3):
+            bs.encode(args.path)
+            bs.sync()
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        reps = 20
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        for _ in range(reps):
+            bs.encode(args.path)
+            bs.sync()
+        d5 = (time.perf_counter() - t5) / reps
+        ctx.profile_enable(False)
+        sk_ms, sk_n = ctx.profile_query(kname)
+        out["shard_1250"] = {"workload": "1250 x 10 s stereo clips, q=high: per-GPU shard of configs[3] split 8 ways",
+                             "value": round(1250 * n_il / d5 / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(d5 * 1e3, 4)}
+        if sk_n:
+            out["shard_1250"]["kernel_ms"] = round(sk_ms / sk_n, 4)
+            out["shard_1250"]["roofline_frac"] = round(ALG_BYTES_PER_SAMPLE * 1250 * n_il / (sk_ms / sk_n / 1e3) / 1e9 / HBM_PEAK_GBS, 4)
+        bs.close()
 
     if not args.no_single_clip and world == 1:
         n180 = 180 * sr * ch

@@ -178,12 +178,14 @@ class Context:
         assert nh.value == hops
         return dict(coeffs=coeffs, q=q, sf_words=sfw)
 
-    def lossy_quantize(self, coeffs, sample_rate, quality):
+    def lossy_quantize(self, coeffs, sample_rate, quality, exact=False):
+        """Device psychoacoustics + quantiser on caller-supplied spectra. exact=False is the quantiser every encode
+        runs; exact=True adds the reference's dB-domain re-check next to the threshold (test yardstick)."""
         c = np.ascontiguousarray(coeffs, np.float32)
         hops, channels = c.shape[0], c.shape[1]
         q = np.zeros((hops, channels, 1024), np.int16)
         sfw = np.zeros((hops, channels, 25), np.uint16)
-        self._chk(self._L.flo_lossy_quantize(self._h, c.ctypes.data, hops, sample_rate, channels, quality,
+        self._chk(self._L.flo_lossy_quantize(self._h, c.ctypes.data, hops, sample_rate, channels, quality, 1 if exact else 0,
                                              q.ctypes.data, sfw.ctypes.data))
         return dict(q=q, sf_words=sfw)
 

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kFinThreads) void crc_slices_kernel(FinishArgs A) {
     __shared__ uint32_t skip[4][256];   // multiplication by x^(8 (kStripe - kBlk))
     __shared__ uint32_t s_red[kFinThreads / 64];
     __shared__ uint32_t s_pw[2];
-    const unsigned clip = blockIdx.y, part = blockIdx.x;
+    const unsigned clip = blockIdx.x, part = blockIdx.y;   // clips in x: gridDim.y stops at 65535
     if (clip >= (unsigned)A.n_clips) return;
     const unsigned t = threadIdx.x;
     const unsigned long long total = A.clip_bytes[clip];
@@ -288,7 +288,7 @@ int launch_finish_files(FinishArgs A, hipStream_t s) {
     memcpy(A.blk_pow, blk, sizeof blk);
     memcpy(A.byte_pow, bytep, sizeof bytep);
     memcpy(A.stripe_pow, stripep, sizeof stripep);
-    hipLaunchKernelGGL(crc_slices_kernel, dim3(A.parts, (unsigned)A.n_clips), dim3(kFinThreads), 0, s, A);
+    hipLaunchKernelGGL(crc_slices_kernel, dim3((unsigned)A.n_clips, A.parts), dim3(kFinThreads), 0, s, A);
     hipLaunchKernelGGL(finish_files_kernel, dim3((unsigned)A.n_clips), dim3(kFinThreads), 0, s, A);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -38,10 +38,10 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
     __shared__ int s_nrec;
     __shared__ __attribute__((aligned(16))) uint8_t sblob[kBlobStage + 16];   // the channel's sparse bytes, staged
     const int lane = (int)threadIdx.x;
-    const unsigned clip = blockIdx.y;
+    const unsigned clip = blockIdx.x;   // clips in x: gridDim.y stops at 65535
     if (clip >= (unsigned)D.n_clips) return;
     const unsigned nframes = D.clip_frames[clip];
-    const unsigned h0 = blockIdx.x * kDecRun;          // first frame of the run = first output block
+    const unsigned h0 = blockIdx.y * kDecRun;          // first frame of the run = first output block
     if (nframes < 2 || h0 + 1 >= nframes) return;
     const unsigned h1 = h0 + kDecRun < nframes - 1 ? h0 + kDecRun : nframes - 1;   // last frame of the run
     float *out = D.out + D.clip_out[clip];
@@ -367,11 +367,11 @@ __global__ __launch_bounds__(64) void ll_decode_kernel(LlDecArgs A) {
 
 // mid/side (decoder.rs:76-90: truncating halves of wrapping sums), interleave, i32 -> f32 (audio_constants.rs:23-26)
 __global__ __launch_bounds__(256) void ll_finish_kernel(LlFinishArgs A) {
-    const unsigned f = blockIdx.y;
+    const unsigned f = blockIdx.x;   // frames in x: gridDim.y stops at 65535
     if (f >= A.n_frames) return;
     const LlFrameDev fr = A.fr[f];
     const float scale = 1.0f / 32767.0f;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < fr.samples; i += gridDim.x * blockDim.x) {
+    for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < fr.samples; i += gridDim.y * blockDim.x) {
         if (fr.mid_side && fr.n_channels == 2) {
             const int m = A.scratch[fr.scratch_off[0] + i], s = A.scratch[fr.scratch_off[1] + i];
             const int l = (int)((unsigned)m + (unsigned)s) / 2, r = (int)((unsigned)m - (unsigned)s) / 2;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void ll_finish_kernel(LlFinishArgs A) {
 int launch_lossy_decode(const LossyDecArgs &A, unsigned max_frames, hipStream_t s) {
     if (max_frames < 2 || !A.n_clips) return 0;
     const unsigned runs = (max_frames - 1 + kDecRun - 1) / kDecRun;
-    hipLaunchKernelGGL(lossy_decode_kernel, dim3(runs, (unsigned)A.n_clips), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(lossy_decode_kernel, dim3((unsigned)A.n_clips, runs), dim3(64), 0, s, A);
     FLO_LAUNCH_CHECK();
     return 0;
 }
@@ -414,7 +414,7 @@ int launch_ll_finish(const LlFinishArgs &A, unsigned max_samples, hipStream_t s)
     if (!A.n_frames || !max_samples) return 0;
     unsigned bx = (max_samples + 255) / 256;
     if (bx > 256) bx = 256;
-    hipLaunchKernelGGL(ll_finish_kernel, dim3(bx, A.n_frames), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(ll_finish_kernel, dim3(A.n_frames, bx), dim3(256), 0, s, A);
     FLO_LAUNCH_CHECK();
     return 0;
 }

@@ -32,6 +32,10 @@ struct ProfRec {
     std::string name;
     hipEvent_t a, b;
 };
+struct ProfSum {   // launches already read out (their events are destroyed)
+    double ms = 0;
+    uint64_t n = 0;
+};
 
 struct flo_ctx {
     int device = 0;
@@ -39,7 +43,8 @@ struct flo_ctx {
     std::string err;
     std::vector<TableSet *> tables;
     bool profile = false;
-    std::vector<ProfRec> prof;
+    std::vector<ProfRec> prof;              // bracketed launches not yet read out
+    std::map<std::string, ProfSum> prof_sum;
     int force_path = 0;
     hipDeviceProp_t prop{};
 };
@@ -77,18 +82,26 @@ extern "C" int flo_ctx_create(int device, flo_ctx **out) {
     }
     flo_ctx *c = new flo_ctx();
     c->device = device;
+    int prev_dev = -1;
+    hipGetDevice(&prev_dev);   // the calling thread's current device is left as it was found
+    auto restore = [&] {
+        if (prev_dev >= 0 && prev_dev != device) hipSetDevice(prev_dev);
+    };
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&c->prop, device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         g_create_err = std::string("device init failed: ") + hipGetErrorString(e);
         delete c;
+        restore();
         return FLO_ERR_DEVICE;
     }
     if (std::string(c->prop.gcnArchName).find("gfx950") == std::string::npos) {
         g_create_err = std::string("device is ") + c->prop.gcnArchName + ", this library carries gfx950 code only";
         hipStreamDestroy(c->stream);
         delete c;
+        restore();
         return FLO_ERR_DEVICE;
     }
+    restore();
     *out = c;
     return FLO_OK;
 }
@@ -136,22 +149,39 @@ extern "C" int flo_ctx_profile_reset(flo_ctx *c) {
         hipEventDestroy(r.b);
     }
     c->prof.clear();
+    c->prof_sum.clear();
+    return FLO_OK;
+}
+// Fold every finished bracket into the per-kernel sums and destroy its events (a long profiled run keeps at most the
+// launches since the last drain alive).
+static int profile_drain(flo_ctx *c, bool wait) {
+    size_t keep = 0;
+    for (size_t i = 0; i < c->prof.size(); i++) {
+        ProfRec &r = c->prof[i];
+        if (!wait && hipEventQuery(r.b) != hipSuccess) {
+            if (keep != i) c->prof[keep] = r;   // not finished yet: stays queued
+            keep++;
+            continue;
+        }
+        float ms = 0;
+        HIPCHK(c, hipEventSynchronize(r.b));
+        HIPCHK(c, hipEventElapsedTime(&ms, r.a, r.b));
+        ProfSum &ps = c->prof_sum[r.name];
+        ps.ms += ms;
+        ps.n++;
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    c->prof.resize(keep);
     return FLO_OK;
 }
 extern "C" int flo_ctx_profile_query(flo_ctx *c, const char *kernel, double *total_ms, uint64_t *launches) {
     if (!c || !kernel) return FLO_ERR_ARG;
-    double tot = 0;
-    uint64_t n = 0;
-    for (auto &r : c->prof) {
-        if (r.name != kernel) continue;
-        float ms = 0;
-        HIPCHK(c, hipEventSynchronize(r.b));
-        HIPCHK(c, hipEventElapsedTime(&ms, r.a, r.b));
-        tot += ms;
-        n++;
-    }
-    if (total_ms) *total_ms = tot;
-    if (launches) *launches = n;
+    int rc = profile_drain(c, true);
+    if (rc != FLO_OK) return rc;
+    auto it = c->prof_sum.find(kernel);
+    if (total_ms) *total_ms = it == c->prof_sum.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == c->prof_sum.end() ? 0 : it->second.n;
     return FLO_OK;
 }
 
@@ -161,6 +191,10 @@ static int timed_launch(flo_ctx *c, const char *name, F &&launch) {
         int rc = launch();
         return rc == 0 ? FLO_OK : fail(c, FLO_ERR_DEVICE, std::string("launch ") + name + " failed: " +
                                                               hipGetErrorString((hipError_t)(rc > 0 ? rc : 1)));
+    }
+    if (c->prof.size() >= 256) {   // bound the queue of live events
+        int drc = profile_drain(c, false);
+        if (drc != FLO_OK) return drc;
     }
     ProfRec r;
     r.name = name;
@@ -274,13 +308,15 @@ struct flo_batch {
     unsigned long long *d_stamps = nullptr;
     int exact = 0;
     // results (host, valid after sync)
-    bool encoded = false, synced = false;
+    bool encoded = false, synced = false, encode_failed = false;
     std::vector<uint64_t> h_clip_bytes;
     std::vector<uint32_t> h_frame_size;
     // lossless
     LosslessPlan *ll = nullptr;
 };
 
+static int auto_form(const flo_batch *b);
+static int alloc_frame_scratch(flo_batch *b);
 static size_t lossy_max_frame_bytes(int ch) { return 12 + 50 * (size_t)ch + (size_t)ch * (4 + 2064); }
 
 extern "C" void flo_batch_destroy(flo_batch *b) {
@@ -390,6 +426,7 @@ extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size
             BCHK(hipMemcpy(b->d_plan, plan.data(), plan.size() * 8, hipMemcpyHostToDevice));
             BCHK(hipMemcpy(b->d_hops, b->hops.data(), n_clips * 4, hipMemcpyHostToDevice));
         }
+        if (auto_form(b) == 2 && (rc = alloc_frame_scratch(b)) != FLO_OK) return bail(rc);
     } else {
         uint8_t level = qol < 0 ? 0 : (qol > 9 ? 9 : (uint8_t)qol);  // with_compression: level.min(9)
         b->qol = level;
@@ -418,7 +455,7 @@ extern "C" int flo_batch_upload(flo_batch *b, size_t clip, const float *pcm) {
     const uint64_t n_copy = b->mode == FLO_MODE_LOSSY ? b->clip_nsf[clip] * b->ch : b->n_il[clip];
     if (n_copy)
         HIPCHK(c, hipMemcpyAsync(b->d_pcm + b->clip_off[clip], pcm, n_copy * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    b->encoded = b->synced = false;
+    b->encoded = b->synced = b->encode_failed = false;
     return FLO_OK;
 }
 
@@ -442,7 +479,24 @@ extern "C" int flo_batch_fill_synthetic(flo_batch *b, uint32_t seed, uint64_t cl
     hipStreamSynchronize(c->stream);
     hipFree(d_off);
     if (e != hipSuccess || rc != 0) return fail(c, FLO_ERR_DEVICE, "synthetic fill failed");
-    b->encoded = b->synced = false;
+    b->encoded = b->synced = b->encode_failed = false;
+    return FLO_OK;
+}
+
+// auto selection of the lossy kernel form (flo_batch_encode with which = 0 and nothing forced)
+static int auto_form(const flo_batch *b) {
+    if (b->ch > 2) return 2;
+    return (b->n_clips * b->ch >= 512) ? (b->ch == 2 ? 3 : 1) : 2;
+}
+// scratch of the frame-parallel form: per-frame masking levels, fixed-size frame slots, frame offsets
+static int alloc_frame_scratch(flo_batch *b) {
+    flo_ctx *c = b->ctx;
+    if (b->d_at || !b->total_frames) return FLO_OK;
+    const size_t n = (size_t)b->total_frames * b->ch * 32 * sizeof(float);
+    HIPCHK(c, hipMalloc(&b->d_at, n));
+    HIPCHK(c, hipMalloc(&b->d_sprev, n));
+    HIPCHK(c, hipMalloc(&b->d_slots, (size_t)b->total_frames * lossy_slot_bytes(b->ch)));
+    HIPCHK(c, hipMalloc(&b->d_frame_off, (size_t)(b->total_frames + 1) * 8));
     return FLO_OK;
 }
 
@@ -479,13 +533,24 @@ static LossyArgs make_args(flo_batch *b) {
     return A;
 }
 
+static int batch_encode_launch(flo_batch *b, int which);
 extern "C" int flo_batch_encode(flo_batch *b, int which) {
     if (!b) return FLO_ERR_ARG;
     flo_ctx *c = b->ctx;
     if (which < 0 || which > 3) return fail(c, FLO_ERR_ARG, "unknown kernel form");
     HIPCHK(c, hipSetDevice(c->device));
-    b->encoded = true;
+    // "encoded" is set only once every launch of this call has been accepted: after a failed encode, sync / fetch /
+    // pack refuse with FLO_ERR_STATE instead of handing out stale or partial bytes
+    b->encoded = false;
     b->synced = false;
+    int erc = batch_encode_launch(b, which);
+    b->encoded = erc == FLO_OK;
+    b->encode_failed = erc != FLO_OK;
+    return erc;
+}
+
+static int batch_encode_launch(flo_batch *b, int which) {
+    flo_ctx *c = b->ctx;
     if (!b->n_clips) return FLO_OK;
     if (b->mode == FLO_MODE_LOSSLESS) {
         std::string err;
@@ -500,7 +565,7 @@ extern "C" int flo_batch_encode(flo_batch *b, int which) {
         if (part) HIPCHK(c, hipMemsetAsync(b->d_pcm + b->clip_off[i] + b->clip_nsf[i] * b->ch, 0, part * sizeof(float), c->stream));
     }
     if (which == 0) which = c->force_path;
-    if (which == 0) which = (b->n_clips * b->ch >= 512) ? (b->ch == 2 ? 3 : 1) : 2;
+    if (which == 0) which = auto_form(b);
     if (b->ch > 2) which = 2;   // more than two channels: the generic frame-parallel kernels
     int rc;
     if (which == 1 || (which == 3 && b->ch != 2)) {
@@ -513,13 +578,9 @@ extern "C" int flo_batch_encode(flo_batch *b, int which) {
         LossyArgs A = make_args(b);
         rc = timed_launch(c, "lossy_chain3", [&] { return launch_lossy_chain3(A, c->stream); });
     } else {   // frame-parallel form
-        if (!b->d_at) {
-            size_t n = (size_t)b->total_frames * b->ch * 32 * sizeof(float);
-            HIPCHK(c, hipMalloc(&b->d_at, n));
-            HIPCHK(c, hipMalloc(&b->d_sprev, n));
-            HIPCHK(c, hipMalloc(&b->d_slots, (size_t)b->total_frames * lossy_slot_bytes(b->ch)));
-            HIPCHK(c, hipMalloc(&b->d_frame_off, (size_t)(b->total_frames + 1) * 8));
-        }
+        // allocated by flo_batch_create when this form is what auto selects; only a forced form allocates here
+        int arc = alloc_frame_scratch(b);
+        if (arc != FLO_OK) return arc;
         LossyArgs A = make_args(b);
         if ((rc = timed_launch(c, "lossy_bands", [&] { return launch_lossy_frames_pass(A, 1, c->stream); })) != FLO_OK) return rc;
         if ((rc = timed_launch(c, "lossy_scan", [&] { return launch_lossy_scan(A, c->stream); })) != FLO_OK) return rc;
@@ -554,6 +615,7 @@ extern "C" int flo_batch_sync(flo_batch *b) {
     flo_ctx *c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!b->encoded && b->encode_failed) return fail(c, FLO_ERR_STATE, "the last flo_batch_encode on this batch failed");
     if (b->encoded && !b->synced) {
         if (b->mode == FLO_MODE_LOSSY) {
             // only the per-clip sizes come back; frame sizes stay on the device (the TOC is written there) and are
@@ -769,7 +831,7 @@ extern "C" int flo_mdct_forward(flo_ctx *c, const float *frames, size_t n_frames
 }
 
 static int analyze_common(flo_ctx *c, const float *pcm, size_t n, const float *in_coeffs, size_t in_hops, uint32_t sr,
-                          uint8_t ch, float quality, float *coeffs, int16_t *q, uint16_t *sfw, size_t *num_hops) {
+                          uint8_t ch, float quality, int exact, float *coeffs, int16_t *q, uint16_t *sfw, size_t *num_hops) {
     flo_batch *b = nullptr;
     size_t n_il = in_coeffs ? (in_hops ? (in_hops - 1) * 1024 * ch : 0) : n;
     if (in_coeffs && in_hops == 0) return FLO_OK;
@@ -792,7 +854,7 @@ static int analyze_common(flo_ctx *c, const float *pcm, size_t n, const float *i
         if (hipMemcpy(d_in, in_coeffs, per * 1024 * 4, hipMemcpyHostToDevice) != hipSuccess)
             return done(fail(c, FLO_ERR_DEVICE, "hipMemcpy"));
         b->d_in_coeffs = d_in;
-        b->exact = 1;
+        b->exact = exact ? 1 : 0;
     } else {
         rc = flo_batch_upload(b, 0, pcm);
         if (rc != FLO_OK) return done(rc);
@@ -811,12 +873,12 @@ static int analyze_common(flo_ctx *c, const float *pcm, size_t n, const float *i
 extern "C" int flo_lossy_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, uint8_t ch, float quality,
                                  float *coeffs, int16_t *q, uint16_t *sfw, size_t *num_hops) {
     if (!c || (n && !pcm)) return FLO_ERR_ARG;
-    return analyze_common(c, pcm, n, nullptr, 0, sr, ch, quality, coeffs, q, sfw, num_hops);
+    return analyze_common(c, pcm, n, nullptr, 0, sr, ch, quality, 0, coeffs, q, sfw, num_hops);
 }
 extern "C" int flo_lossy_quantize(flo_ctx *c, const float *coeffs, size_t num_hops, uint32_t sr, uint8_t ch,
-                                  float quality, int16_t *q, uint16_t *sfw) {
+                                  float quality, int exact, int16_t *q, uint16_t *sfw) {
     if (!c || (num_hops && !coeffs)) return FLO_ERR_ARG;
-    return analyze_common(c, nullptr, 0, coeffs, num_hops, sr, ch, quality, nullptr, q, sfw, nullptr);
+    return analyze_common(c, nullptr, 0, coeffs, num_hops, sr, ch, quality, exact, nullptr, q, sfw, nullptr);
 }
 
 extern "C" int flo_sparse_pack(flo_ctx *c, const int16_t *q, size_t n_vec, uint8_t *out, size_t out_cap,

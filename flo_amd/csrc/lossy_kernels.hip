@@ -717,10 +717,10 @@ __global__ __launch_bounds__(64) void lossy_frame_n_kernel(LossyArgs A) {
 // Writes the state seen BEFORE each frame.
 constexpr int kScanBlock = 64;
 __global__ void lossy_scan_kernel(LossyArgs A) {
-    const unsigned clip = blockIdx.y;
+    const unsigned clip = blockIdx.x;   // clips in x: gridDim.y stops at 65535
     if (clip >= (unsigned)A.n_clips) return;
     const unsigned hops = A.clip_hops[clip];
-    const unsigned blk = blockIdx.x;
+    const unsigned blk = blockIdx.y;
     const unsigned fs = blk * kScanBlock;
     if (fs >= hops) return;
     const unsigned ch = threadIdx.x >> 5, band = threadIdx.x & 31u;
@@ -832,29 +832,65 @@ __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigne
     if (lane == 0) sizes[w] = P.total;
 }
 
-// Copy every clip's DATA chunk into one caller-provided buffer, back to back at 16-byte aligned offsets (the packed
-// form handed to the RCCL gather). 16-byte units: sources are 16-byte aligned by construction.
+// Copy every clip's DATA chunk or finished file into one caller-provided buffer, back to back at 16-byte aligned
+// offsets (the packed form handed to the RCCL gather). Destinations are 16-byte aligned; sources need not be (a
+// finished file starts 74 + 20 frames bytes in front of its aligned DATA chunk): each 16-byte unit is assembled from the
+// two aligned units that cover it, and the bytes behind a clip's last byte are written as zeros. The aligned reads stay
+// inside the batch's output allocation (it starts aligned and ends with slack).
 __global__ void pack_streams_kernel(const uint8_t *src, const unsigned long long *src_off, const unsigned long long *dst_off,
                                     const unsigned long long *sizes, int n_clips, uint8_t *dst) {
-    const int clip = blockIdx.y;
+    const int clip = blockIdx.x;   // clips in x: gridDim.y stops at 65535
     if (clip >= n_clips) return;
-    const unsigned long long n16 = (sizes[clip] + 15) >> 4;
-    const uint4 *s = reinterpret_cast<const uint4 *>(src + src_off[clip]);
+    const unsigned long long size = sizes[clip];
+    const unsigned long long n16 = (size + 15) >> 4;
+    const uint8_t *sp = src + src_off[clip];
+    const unsigned mis = (unsigned)((uintptr_t)sp & 15u);
+    const uint4 *s = reinterpret_cast<const uint4 *>(sp - mis);
+    const unsigned wq = mis >> 2, sh = (mis & 3u) * 8u;
     uint4 *d = reinterpret_cast<uint4 *>(dst + dst_off[clip]);
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
-         i += (unsigned long long)gridDim.x * blockDim.x)
-        d[i] = s[i];
+    for (unsigned long long i = (unsigned long long)blockIdx.y * blockDim.x + threadIdx.x; i < n16;
+         i += (unsigned long long)gridDim.y * blockDim.x) {
+        uint4 v = s[i];
+        if (mis) {
+            const uint4 hi = s[i + 1];
+            const uint32_t w[8] = {v.x, v.y, v.z, v.w, hi.x, hi.y, hi.z, hi.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // words wq + j and wq + j + 1, selected without run-time register indexing (wq is uniform)
+                uint32_t lo = 0, up = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    lo = wq == (unsigned)q ? w[q + j] : lo;
+                    up = wq == (unsigned)q ? w[q + j + 1 < 8 ? q + j + 1 : 7] : up;
+                }
+                o[j] = sh ? (lo >> sh) | (up << (32u - sh)) : lo;
+            }
+            v = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        if (i == n16 - 1 && (size & 15u)) {   // zero the padding behind the clip's last byte
+            const unsigned keep = (unsigned)(size & 15u);
+            uint32_t o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int kb = (int)keep - 4 * j;   // bytes of word j that belong to the clip
+                o[j] = kb >= 4 ? o[j] : (kb <= 0 ? 0u : (o[j] & ((1u << (8 * kb)) - 1u)));
+            }
+            v = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        d[i] = v;
+    }
 }
 
 // integer-exact synthetic PCM (include/flo_synth.h), one thread per 4 interleaved samples
 __global__ void synth_fill_kernel(float *pcm, const unsigned long long *clip_off, const unsigned long long *clip_nsf,
                                   int n_clips, int nch, uint32_t seed, unsigned long long clip_id0) {
-    const unsigned clip = blockIdx.y;
+    const unsigned clip = blockIdx.x;   // clips in x: gridDim.y stops at 65535
     if (clip >= (unsigned)n_clips) return;
     const unsigned long long n = clip_nsf[clip] * (unsigned long long)nch;
     float *p = pcm + clip_off[clip];
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (unsigned long long)gridDim.x * blockDim.x) {
+    for (unsigned long long i = (unsigned long long)blockIdx.y * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.y * blockDim.x) {
         const unsigned long long sf = i / (unsigned)nch;
         const unsigned ch = (unsigned)(i % (unsigned)nch);
         p[i] = flo_synth_sample(seed, clip_id0 + clip, ch, sf);
@@ -949,7 +985,7 @@ int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s) {
 }
 int launch_lossy_scan(const LossyArgs &A, hipStream_t s) {
     unsigned max_hops = (unsigned)A.max_hops;
-    hipLaunchKernelGGL(lossy_scan_kernel, dim3((max_hops + kScanBlock - 1) / kScanBlock, A.n_clips), dim3(32 * A.nch), 0, s, A);
+    hipLaunchKernelGGL(lossy_scan_kernel, dim3(A.n_clips, (max_hops + kScanBlock - 1) / kScanBlock), dim3(32 * A.nch), 0, s, A);
     FLO_LAUNCH_CHECK();
     return 0;
 }
@@ -972,13 +1008,13 @@ int launch_sparse_only(const short *q, unsigned long long n, uint8_t *slots, uin
 }
 int launch_pack_streams(const uint8_t *src, const unsigned long long *src_off, const unsigned long long *dst_off,
                         const unsigned long long *sizes, int n_clips, uint8_t *dst, hipStream_t s) {
-    hipLaunchKernelGGL(pack_streams_kernel, dim3(8, n_clips), dim3(256), 0, s, src, src_off, dst_off, sizes, n_clips, dst);
+    hipLaunchKernelGGL(pack_streams_kernel, dim3(n_clips, 8), dim3(256), 0, s, src, src_off, dst_off, sizes, n_clips, dst);
     FLO_LAUNCH_CHECK();
     return 0;
 }
 int launch_synth_fill(float *pcm, const unsigned long long *clip_off, const unsigned long long *clip_nsf, int n_clips,
                       int nch, uint32_t seed, unsigned long long clip_id0, hipStream_t s) {
-    hipLaunchKernelGGL(synth_fill_kernel, dim3(64, n_clips), dim3(256), 0, s, pcm, clip_off, clip_nsf, n_clips, nch,
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(n_clips, 64), dim3(256), 0, s, pcm, clip_off, clip_nsf, n_clips, nch,
                        seed, clip_id0);
     FLO_LAUNCH_CHECK();
     return 0;

@@ -162,9 +162,11 @@ int flo_lossy_analyze(flo_ctx *ctx, const float *pcm, size_t n_interleaved, uint
 /* quantise + serialise given MDCT coefficients (device quantiser fed caller-supplied spectra):
  * coeffs [hops][ch][1024] -> quantized [hops][ch][1024], sf_words [hops][ch][25]. Replaces
  * PsychoacousticModel::calculate_smr + TransformEncoder::quantize_coefficients
- * (lossy/psychoacoustic.rs:151-235, lossy/encoder.rs:109-154) */
+ * (lossy/psychoacoustic.rs:151-235, lossy/encoder.rs:109-154). exact = 0 runs the quantiser exactly as every encode
+ * entry point does (keep test in the amplitude domain); exact = 1 additionally re-decides coefficients within 1e-5
+ * of the threshold with the reference's own dB-domain f32 expression (a test yardstick, never used by an encode). */
 int flo_lossy_quantize(flo_ctx *ctx, const float *coeffs, size_t num_hops, uint32_t sample_rate, uint8_t channels,
-                       float quality, int16_t *quantized, uint16_t *sf_words);
+                       float quality, int exact, int16_t *quantized, uint16_t *sf_words);
 /* serialize_sparse on device: n_vec vectors of 1024 i16 -> bytes; out_off[n_vec+1] prefix offsets.
  * Replaces lossy/encoder.rs:284-314 */
 int flo_sparse_pack(flo_ctx *ctx, const int16_t *q, size_t n_vec, uint8_t *out, size_t out_cap, uint32_t *out_off);

@@ -13,7 +13,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FLO_HD __host__ __device__ static inline
 #else
 #define FLO_HD static inline

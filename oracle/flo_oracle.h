@@ -85,6 +85,11 @@ size_t flo_o_lossy_num_hops(size_t n_interleaved, uint8_t channels);
 size_t flo_o_lossy_analyze(const float *pcm, size_t n_interleaved, uint32_t sample_rate, uint8_t channels,
                            float quality, float *coeffs, float *smr, int16_t *q, float *sf, uint16_t *sf_words);
 
+/* the same driver with the MDCT evaluated in double precision from its definition and rounded to f32 (an accuracy
+ * yardstick for the f32 FFTs of the oracle and of the device; not a reference function) */
+size_t flo_o_lossy_analyze_f64mdct(const float *pcm, size_t n_interleaved, uint32_t sample_rate, uint8_t channels,
+                                   float quality, float *coeffs, float *smr, int16_t *q, float *sf, uint16_t *sf_words);
+
 /* ---- top-level API (lossless/encoder.rs:32-45, lossy/encoder.rs:167-239, lib.rs:296-352) ---- */
 int flo_o_encode_lossless(const float *pcm, size_t n_interleaved, uint32_t sample_rate, uint8_t channels,
                           uint8_t bit_depth, uint8_t level, const uint8_t *meta, size_t meta_len,

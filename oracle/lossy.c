@@ -185,6 +185,27 @@ void flo_o_mdct_forward_direct_f64(const float *samples, size_t n, int window_ty
     free(w);
 }
 
+/* The same evaluation for the long block with the cosine taken from an exact-period table: the argument is
+ * pi/4096 * (2i + 1 + 1024)(2k + 1), so the integer product mod 8192 indexes cos(pi j / 4096). Output rounded to f32:
+ * "the transform the reference would compute with an exact FFT" — the yardstick the kept-integer tests measure both
+ * the oracle's f32 FFT and the device's against (test infrastructure only; not a reference function). */
+static void mdct_fwd_f64_long(const float *window, const float *samples, float *out) {
+    static double ctab[8192];
+    static int have = 0;
+    if (!have) {
+        for (int j = 0; j < 8192; j++) ctab[j] = cos(M_PI * (double)j / 4096.0);
+        have = 1;
+    }
+    double xw[2048];
+    for (size_t i = 0; i < 2048; i++) xw[i] = (double)(samples[i] * window[i]); /* windowing product is f32 (mdct.rs:174-178) */
+    for (size_t k = 0; k < 1024; k++) {
+        double acc = 0.0;
+        const unsigned kk = 2u * (unsigned)k + 1u;
+        for (size_t i = 0; i < 2048; i++) acc += xw[i] * ctab[((2u * (unsigned)i + 1025u) * kk) & 8191u];
+        out[k] = (float)acc;
+    }
+}
+
 /* ------------------------------------------------------------------ psychoacoustic.rs */
 static const float BARK_BAND_EDGES[26] = {0.0f,    100.0f,  200.0f,  300.0f,  400.0f,  510.0f,   630.0f,
                                           770.0f,  920.0f,  1080.0f, 1270.0f, 1480.0f, 1720.0f,  2000.0f,
@@ -427,9 +448,9 @@ size_t flo_o_lossy_num_hops(size_t n_interleaved, uint8_t channels) { /* :174-17
 }
 
 /* encoder.rs:167-239 (driver) + :63-106 (encode_frame). Captures intermediates when asked. */
-static int lossy_drive(const float *samples, size_t n, uint32_t sample_rate, uint8_t channels, float quality,
-                       o_frame **frames_out, size_t *n_frames_out, float *cap_coeffs, float *cap_smr,
-                       int16_t *cap_q, float *cap_sf, uint16_t *cap_sfw) {
+static int lossy_drive_ex(const float *samples, size_t n, uint32_t sample_rate, uint8_t channels, float quality,
+                          o_frame **frames_out, size_t *n_frames_out, float *cap_coeffs, float *cap_smr,
+                          int16_t *cap_q, float *cap_sf, uint16_t *cap_sfw, int f64_mdct) {
     const size_t block_samples = 2048, hop_size = 1024;
     size_t ch = channels;
     if (quality < 0.0f) quality = 0.0f; /* TransformEncoder::new: quality.clamp(0,1) */
@@ -467,7 +488,8 @@ static int lossy_drive(const float *samples, size_t n, uint32_t sample_rate, uin
         const float *fs = padded + start;
         for (size_t c = 0; c < ch; c++) {
             for (size_t i = 0; i < block_samples; i++) frame_data[i] = fs[i * ch + c];
-            mdct_fwd(&mdct, frame_data, coeffs);
+            if (f64_mdct) mdct_fwd_f64_long(mdct.window, frame_data, coeffs);
+            else mdct_fwd(&mdct, frame_data, coeffs);
             psy_calculate_smr(&psy[c], coeffs, smr);
             quantize_coefficients(sample_rate, quality, coeffs, smr, q + c * 1024, sf + c * NUM_BARK_BANDS);
             size_t o = (hop * ch + c);
@@ -506,6 +528,13 @@ static int lossy_drive(const float *samples, size_t n, uint32_t sample_rate, uin
     return 0;
 }
 
+static int lossy_drive(const float *samples, size_t n, uint32_t sample_rate, uint8_t channels, float quality,
+                       o_frame **frames_out, size_t *n_frames_out, float *cap_coeffs, float *cap_smr,
+                       int16_t *cap_q, float *cap_sf, uint16_t *cap_sfw) {
+    return lossy_drive_ex(samples, n, sample_rate, channels, quality, frames_out, n_frames_out, cap_coeffs, cap_smr, cap_q,
+                          cap_sf, cap_sfw, 0);
+}
+
 int lossy_encode_frames(const float *samples, size_t n, uint32_t sample_rate, uint8_t channels, float quality,
                         o_frame **frames, size_t *n_frames) {
     return lossy_drive(samples, n, sample_rate, channels, quality, frames, n_frames, NULL, NULL, NULL, NULL, NULL);
@@ -515,6 +544,15 @@ size_t flo_o_lossy_analyze(const float *pcm, size_t n, uint32_t sample_rate, uin
                            float *coeffs, float *smr, int16_t *q, float *sf, uint16_t *sf_words) {
     size_t nf = 0;
     lossy_drive(pcm, n, sample_rate, channels, quality, NULL, &nf, coeffs, smr, q, sf, sf_words);
+    return nf;
+}
+
+/* The clip driver with the transform evaluated in double precision (see mdct_fwd_f64_long): same psychoacoustic
+ * model, quantiser and scale words as the reference path behind it. */
+size_t flo_o_lossy_analyze_f64mdct(const float *pcm, size_t n, uint32_t sample_rate, uint8_t channels, float quality,
+                                   float *coeffs, float *smr, int16_t *q, float *sf, uint16_t *sf_words) {
+    size_t nf = 0;
+    lossy_drive_ex(pcm, n, sample_rate, channels, quality, NULL, &nf, coeffs, smr, q, sf, sf_words, 1);
     return nf;
 }
 

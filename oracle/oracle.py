@@ -77,8 +77,10 @@ def lib():
         L.flo_o_lossy_num_hops.restype = C.c_size_t
         L.flo_o_lossy_num_hops.argtypes = [C.c_size_t, C.c_uint8]
         L.flo_o_lossy_analyze.restype = C.c_size_t
+        L.flo_o_lossy_analyze_f64mdct.restype = C.c_size_t
         L.flo_o_lossy_analyze.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint8, C.c_float,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.flo_o_lossy_analyze_f64mdct.argtypes = L.flo_o_lossy_analyze.argtypes
         L.flo_o_encode_lossless.restype = C.c_int
         L.flo_o_encode_lossless.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint8,
                                             C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -224,8 +226,9 @@ def deserialize_sparse(data: bytes, num_coeffs=1024):
     return out
 
 
-def lossy_analyze(pcm, sample_rate, channels, quality):
-    """Returns dict of per-frame intermediates of the reference lossy encoder, [hops][ch][...]."""
+def lossy_analyze(pcm, sample_rate, channels, quality, f64_mdct=False):
+    """Returns dict of per-frame intermediates of the reference lossy encoder, [hops][ch][...].
+    f64_mdct: evaluate the transform in double precision from its definition (accuracy yardstick for the f32 FFTs)."""
     p = _f32(pcm)
     nh = lib().flo_o_lossy_num_hops(p.size, channels)
     coeffs = np.zeros((nh, channels, 1024), np.float32)
@@ -233,8 +236,9 @@ def lossy_analyze(pcm, sample_rate, channels, quality):
     q = np.zeros((nh, channels, 1024), np.int16)
     sf = np.zeros((nh, channels, 25), np.float32)
     sfw = np.zeros((nh, channels, 25), np.uint16)
-    got = lib().flo_o_lossy_analyze(p.ctypes.data, p.size, sample_rate, channels, quality, coeffs.ctypes.data,
-                                    smr.ctypes.data, q.ctypes.data, sf.ctypes.data, sfw.ctypes.data)
+    fn = lib().flo_o_lossy_analyze_f64mdct if f64_mdct else lib().flo_o_lossy_analyze
+    got = fn(p.ctypes.data, p.size, sample_rate, channels, quality, coeffs.ctypes.data,
+             smr.ctypes.data, q.ctypes.data, sf.ctypes.data, sfw.ctypes.data)
     assert got == nh
     return dict(coeffs=coeffs, smr=smr, q=q, sf=sf, sf_words=sfw)
 

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects the profile evidence bench.py's roofline numbers are checked against. Run on the GPU box from the repo
-# root:  profiles/collect.sh r01   -> gpurun_out/prof_r01/{stats,fetch,write,sq}/ + gpurun_out/prof_r01/summary.json
+# root:  profiles/collect.sh r02   -> gpurun_out/prof_r02/{stats,fetch,write,sq}/ + gpurun_out/prof_r02/summary.json
 # Passes are separate on purpose: --kernel-trace --stats alone for durations; FETCH_SIZE and WRITE_SIZE do not fit one
 # TCC pass; the SQ counters take another. No --pmc pass is combined with any API/runtime trace.
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp

@@ -35,7 +35,15 @@ def counters(d):
 
 def main():
     d = sys.argv[1]
-    out = {"source": d, "kernels": {}}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench                                    # kernel_source_sha(): what bench.py checks before quoting the counters
+    out = {"source": d, "kernel_source_sha": bench.kernel_source_sha(),
+           "clips_per_gpu": int(sys.argv[2]) if len(sys.argv) > 2 else 10000,
+           "clip_seconds": float(sys.argv[3]) if len(sys.argv) > 3 else 10.0,
+           "fetch_correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md: gfx950 tallies 128-B requests of wide coalesced reads at "
+                               "64 B); calibrated for 16-B-per-lane streams only - kernels that read one dword per lane "
+                               "(ll_prepare, the chain kernels' 4- and 8-byte PCM loads) may be over-counted by up to 2x",
+           "kernels": {}}
     for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True):
         with open(f, newline="") as fh:
             for r in csv.DictReader(fh):

@@ -69,3 +69,40 @@ def test_public_headers_compile_as_plain_c99(tmp_path):
     src.write_text('#include "flo_hip.h"\n#include "flo_synth.h"\nint main(void) { return FLO_OK; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
                            "-fsyntax-only", str(src)])
+
+
+def _build_native_caller(tmp_path):
+    """tests/native/abi_smoke.c linked against libflo_hip.so with gcc: a caller with no Python in the loop."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc")
+    exe = tmp_path / "abi_smoke"
+    libdir = os.path.join(ROOT, "flo_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "native", "abi_smoke.c"), "-o", str(exe),
+                           "-L", libdir, "-lflo_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    gold = os.path.join(ROOT, "tests", "golden", "examples")
+    return [str(exe), os.path.join(gold, "audio_lossless.flo"), os.path.join(gold, "audio_lossy.flo")]
+
+
+def test_native_c_caller_links_and_fails_loudly_without_gpu(tmp_path):
+    import subprocess
+    import torch
+    cmd = _build_native_caller(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the run itself is test_native_c_caller_reproduces_the_reference_files")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert "no HIP device" in r.stderr or "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_native_c_caller_reproduces_the_reference_files(tmp_path):
+    # flo_encode_lossless / flo_encode_lossy / flo_decode driven from C on BASELINE configs[0]'s input: header + TOC +
+    # DATA of the lossless file and the DATA chunk of the lossy file equal the files the reference wrote
+    import subprocess
+    r = subprocess.run(_build_native_caller(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "abi_smoke ok" in r.stdout

@@ -62,17 +62,68 @@ def test_sparse_pack_bit_exact(ctx):
         assert got[i] == O.serialize_sparse(p), i
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["shipped", "exact"])
 @pytest.mark.parametrize("q", [0.0, 0.35, 0.55, 0.75, 1.0])
-def test_quantiser_fed_oracle_spectra(ctx, q):
+def test_quantiser_fed_oracle_spectra(ctx, q, exact):
     # isolates psychoacoustics + quantiser + scale words from the transform: identical coefficients in,
-    # identical integers out (up to libm-vs-device log rounding on a vanishing fraction)
+    # identical integers out (up to libm-vs-device log rounding on a vanishing fraction).
+    # "shipped" is the instantiation every encode entry point runs (amplitude-domain keep test, quantise<., EXACT=false>);
+    # "exact" adds the reference's dB-domain re-check next to the threshold. Both meet the same bound.
     pcm = signals.music_like(44100, 30000, 2, seed=3)
     o = O.lossy_analyze(pcm, 44100, 2, q)
-    g = ctx.lossy_quantize(o["coeffs"], 44100, q)
+    g = ctx.lossy_quantize(o["coeffs"], 44100, q, exact=exact)
+    flips = ((g["q"] != 0) != (o["q"] != 0)).mean()
     mism = (g["q"] != o["q"]).mean()
-    assert mism <= 1e-4, mism      # keep/drop flips from the band-energy summation order (device tree vs sequential)
+    print(f"q={q} exact={exact}: keep/drop flip rate {flips:.2e}, integer mismatch rate {mism:.2e}")
+    assert flips <= 1e-4, flips    # SURVEY 8c(ii) allows 5e-4; the band-energy summation order is the only difference
+    assert mism <= 1e-4, mism
     assert np.abs(g["sf_words"].astype(int) - o["sf_words"].astype(int)).max() <= 1
     assert (g["sf_words"] != o["sf_words"]).mean() <= 1e-3
+
+
+def test_shipped_quantiser_on_a_long_clip_reports_its_flip_rate(ctx):
+    # the same isolation on ten seconds of the bench's own synthetic signal (864 frame-channels, 885 k coefficients),
+    # production instantiation only: the measured keep/drop flip rate against the oracle's decisions
+    pcm = O.synth_clip(441000, 2, 0xF10A0D10, 7)
+    o = O.lossy_analyze(pcm, 44100, 2, 0.55)
+    g = ctx.lossy_quantize(o["coeffs"], 44100, 0.55, exact=False)
+    flips = int(((g["q"] != 0) != (o["q"] != 0)).sum())
+    print(f"shipped quantiser, 10 s synthetic clip: {flips} keep/drop flips in {o['q'].size} coefficients ({flips / o['q'].size:.2e})")
+    assert flips <= 1e-4 * o["q"].size
+    assert (g["q"] != o["q"]).mean() <= 1e-4
+
+
+@pytest.mark.parametrize("q", [0.35, 0.55, 0.75, 1.0])
+def test_kept_integers_are_no_further_from_an_exact_transform_than_the_oracle(ctx, q):
+    """SURVEY 8c(ii) asked for |dq| <= 1 among coefficients kept by both; an f32 FFT cannot deliver that in quiet
+    bands (absolute noise ~1e-7 of the frame maximum times a band gain of up to 30000 / band_max). The measurement
+    that justifies the relaxed bound of compare_lossy_stage: run the SAME psychoacoustic model and quantiser behind
+    a transform evaluated in double precision (oracle, f64_mdct=True) and require, band by band, that the device's
+    integers are no further from that truth than the pinned oracle's own f32 FFT puts them, plus one rounding step:
+        max_band |q_dev - q_f64|  <=  max_band |q_oracle - q_f64| + 1."""
+    band = O.psy_tables(44100)[1].astype(np.int64)
+    worst_dev = worst_orc = 0
+    for seed, maker in ((3, lambda: signals.music_like(44100, 30000, 2, seed=3)), (0, lambda: O.synth_clip(40000, 2, 0xF10A0D10, 11))):
+        pcm = maker()
+        f = O.lossy_analyze(pcm, 44100, 2, q, f64_mdct=True)
+        o = O.lossy_analyze(pcm, 44100, 2, q)
+        g = ctx.lossy_analyze(pcm, 44100, 2, q)
+        qf, qo, qg = (x["q"].astype(np.int64) for x in (f, o, g))
+        kept = (qf != 0) & (qo != 0) & (qg != 0)
+        d_dev = np.where(kept, np.abs(qg - qf), 0)
+        d_orc = np.where(kept, np.abs(qo - qf), 0)
+        for b in range(25):
+            sel = band == b
+            if not sel.any():
+                continue
+            md, mo = d_dev[..., sel].max(axis=-1), d_orc[..., sel].max(axis=-1)      # [hops][ch]
+            assert (md <= mo + 1).all(), (q, seed, b, int((md - mo).max()))
+        worst_dev, worst_orc = max(worst_dev, int(d_dev.max())), max(worst_orc, int(d_orc.max()))
+        # and the device transform itself is at least as close to the exact one as the oracle's FFT
+        e_dev = np.sqrt(((g["coeffs"].astype(np.float64) - f["coeffs"]) ** 2).sum())
+        e_orc = np.sqrt(((o["coeffs"].astype(np.float64) - f["coeffs"]) ** 2).sum())
+        assert e_dev <= 1.5 * e_orc + 1e-12, (e_dev, e_orc)
+    print(f"q={q}: worst |q - q_f64| among kept coefficients: device {worst_dev}, oracle {worst_orc}")
 
 
 @pytest.mark.parametrize("ch,q", [(1, 0.55), (2, 0.35), (2, 0.55), (2, 1.0), (1, 0.0)])
