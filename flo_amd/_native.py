@@ -96,7 +96,7 @@ def lib():
     L.flo_mdct_forward.argtypes = [vp, vp, sz, vp]
     L.flo_lossy_analyze.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_float, vp, vp, vp, C.POINTER(sz)]
     L.flo_lossy_quantize.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_float, C.c_int, vp, vp]
-    L.flo_sparse_pack.argtypes = [vp, vp, sz, vp, sz, vp]
+    L.flo_sparse_pack.argtypes = [vp, vp, sz, C.c_int, vp, sz, vp]
     L.flo_decode.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
     L.flo_decode_lossless_i32.argtypes = L.flo_decode.argtypes
     L.flo_probe_container.argtypes = [C.c_char_p, sz, C.POINTER(ContainerInfo), C.c_char_p, sz]

@@ -189,12 +189,14 @@ class Context:
                                              q.ctypes.data, sfw.ctypes.data))
         return dict(q=q, sf_words=sfw)
 
-    def sparse_pack(self, q):
+    def sparse_pack(self, q, form=0):
+        """serialize_sparse on the device. form 0: as the encoder packs (ballot form, general form for dense vectors);
+        form 1: the general form for every vector."""
         q = np.ascontiguousarray(q, np.int16).reshape(-1, 1024)
         n = q.shape[0]
         out = np.zeros(n * 2080, np.uint8)
         off = np.zeros(n + 1, np.uint32)
-        self._chk(self._L.flo_sparse_pack(self._h, q.ctypes.data, n, out.ctypes.data, out.size, off.ctypes.data))
+        self._chk(self._L.flo_sparse_pack(self._h, q.ctypes.data, n, form, out.ctypes.data, out.size, off.ctypes.data))
         return [out[off[i]:off[i + 1]].tobytes() for i in range(n)]
 
     # -- profiling hooks --------------------------------------------------------------------------------------

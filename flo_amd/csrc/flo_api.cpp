@@ -131,7 +131,7 @@ extern "C" int flo_ctx_device_info(const flo_ctx *c, char *name, size_t cap, int
 }
 extern "C" void *flo_ctx_stream(flo_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int flo_ctx_force_path(flo_ctx *c, int which) {
-    if (!c || which < 0 || which > 3) return FLO_ERR_ARG;
+    if (!c || which < 0 || which > 4) return FLO_ERR_ARG;
     c->force_path = which;
     return FLO_OK;
 }
@@ -295,7 +295,7 @@ struct flo_batch {
     uint8_t *d_out = nullptr;
     uint32_t *d_frame_size = nullptr;
     uint64_t *d_clip_bytes = nullptr;
-    uint32_t *d_crc = nullptr, *d_part = nullptr;
+    uint32_t *d_crc = nullptr, *d_part = nullptr, *d_next = nullptr;
     float *d_at = nullptr, *d_sprev = nullptr;
     uint8_t *d_slots = nullptr;
     uint64_t *d_frame_off = nullptr;
@@ -324,7 +324,7 @@ extern "C" void flo_batch_destroy(flo_batch *b) {
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
     void *ptrs[] = {b->d_pcm, b->d_plan, b->d_hops, b->d_out, b->d_frame_size, b->d_clip_bytes, b->d_crc, b->d_part, b->d_at,
-                    b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw, b->d_pack_plan};
+                    b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw, b->d_pack_plan, b->d_next};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (b->ll) lossless_plan_destroy(b->ll);
@@ -421,6 +421,7 @@ extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size
         BCHK(hipMalloc(&b->d_frame_size, (b->total_frames + 1) * 4));
         BCHK(hipMalloc(&b->d_clip_bytes, (n_clips + 1) * 8));
         BCHK(hipMalloc(&b->d_crc, (n_clips + 1) * 4));
+        BCHK(hipMalloc(&b->d_next, 16));
         BCHK(hipMalloc(&b->d_part, (n_clips * finish_parts_for(n_clips) + 1) * 4));
         if (n_clips) {
             BCHK(hipMemcpy(b->d_plan, plan.data(), plan.size() * 8, hipMemcpyHostToDevice));
@@ -486,7 +487,7 @@ extern "C" int flo_batch_fill_synthetic(flo_batch *b, uint32_t seed, uint64_t cl
 // auto selection of the lossy kernel form (flo_batch_encode with which = 0 and nothing forced)
 static int auto_form(const flo_batch *b) {
     if (b->ch > 2) return 2;
-    return (b->n_clips * b->ch >= 512) ? (b->ch == 2 ? 3 : 1) : 2;
+    return (b->n_clips * b->ch >= 512) ? (b->ch == 2 ? 4 : 1) : 2;
 }
 // scratch of the frame-parallel form: per-frame masking levels, fixed-size frame slots, frame offsets
 static int alloc_frame_scratch(flo_batch *b) {
@@ -530,6 +531,8 @@ static LossyArgs make_args(flo_batch *b) {
     A.in_coeffs = b->d_in_coeffs;
     A.exact = b->exact;
     A.dbg_stamps = b->d_stamps;
+    A.next_clip = b->d_next;
+    A.n_cus = b->ctx->prop.multiProcessorCount;
     return A;
 }
 
@@ -537,7 +540,7 @@ static int batch_encode_launch(flo_batch *b, int which);
 extern "C" int flo_batch_encode(flo_batch *b, int which) {
     if (!b) return FLO_ERR_ARG;
     flo_ctx *c = b->ctx;
-    if (which < 0 || which > 3) return fail(c, FLO_ERR_ARG, "unknown kernel form");
+    if (which < 0 || which > 4) return fail(c, FLO_ERR_ARG, "unknown kernel form");
     HIPCHK(c, hipSetDevice(c->device));
     // "encoded" is set only once every launch of this call has been accepted: after a failed encode, sync / fetch /
     // pack refuse with FLO_ERR_STATE instead of handing out stale or partial bytes
@@ -568,7 +571,12 @@ static int batch_encode_launch(flo_batch *b, int which) {
     if (which == 0) which = auto_form(b);
     if (b->ch > 2) which = 2;   // more than two channels: the generic frame-parallel kernels
     int rc;
-    if (which == 1 || (which == 3 && b->ch != 2)) {
+    if (which == 4 && b->exact) which = 3;
+    if (which == 4 && b->ch == 2) {   // stereo: one lock-step transform wave + one packer wave per clip
+        LossyArgs A = make_args(b);
+        HIPCHK(c, hipMemsetAsync(b->d_next, 0, 4, c->stream));   // the batch-wide clip counter of the persistent workgroups
+        rc = timed_launch(c, "lossy_chain2x", [&] { return launch_lossy_chain2x(A, c->stream); });
+    } else if (which == 1 || ((which == 3 || which == 4) && b->ch != 2)) {
 #ifdef FLO_STAMPS
         if (!b->d_stamps) HIPCHK(c, hipMalloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
 #endif
@@ -881,9 +889,9 @@ extern "C" int flo_lossy_quantize(flo_ctx *c, const float *coeffs, size_t num_ho
     return analyze_common(c, nullptr, 0, coeffs, num_hops, sr, ch, quality, exact, nullptr, q, sfw, nullptr);
 }
 
-extern "C" int flo_sparse_pack(flo_ctx *c, const int16_t *q, size_t n_vec, uint8_t *out, size_t out_cap,
+extern "C" int flo_sparse_pack(flo_ctx *c, const int16_t *q, size_t n_vec, int form, uint8_t *out, size_t out_cap,
                                uint32_t *out_off) {
-    if (!c || (n_vec && (!q || !out || !out_off))) return FLO_ERR_ARG;
+    if (!c || (n_vec && (!q || !out || !out_off)) || form < 0 || form > 1) return FLO_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (out_off) out_off[0] = 0;
     if (!n_vec) return FLO_OK;
@@ -895,7 +903,7 @@ extern "C" int flo_sparse_pack(flo_ctx *c, const int16_t *q, size_t n_vec, uint8
     if (e == hipSuccess) e = hipMalloc(&d_sizes, n_vec * 4);
     if (e == hipSuccess) e = hipMemcpyAsync(d_q, q, n_vec * 2048, hipMemcpyHostToDevice, c->stream);
     int lrc = 0;
-    if (e == hipSuccess) lrc = launch_sparse_only(d_q, n_vec, d_slots, d_sizes, c->stream);
+    if (e == hipSuccess) lrc = launch_sparse_only(d_q, n_vec, d_slots, d_sizes, form, c->stream);
     std::vector<uint8_t> slots(n_vec * 2080);
     std::vector<uint32_t> sizes(n_vec);
     if (e == hipSuccess && lrc == 0) e = hipMemcpyAsync(slots.data(), d_slots, slots.size(), hipMemcpyDeviceToHost, c->stream);

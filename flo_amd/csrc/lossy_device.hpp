@@ -51,7 +51,11 @@ struct LossyDevTables {
 
 constexpr int kXchStride = 9;            // complex elements per exchange row (8 + 1 pad)
 constexpr int kXchFloats = 64 * kXchStride * 2;  // 1152 floats per channel
-constexpr int kCoefFloats = 1280;        // 1024 coefficients, 4 floats of padding per 16
+#ifdef FLO_COEF_PAD16
+constexpr int kCoefFloats = 1280;
+#else
+constexpr int kCoefFloats = 1152;        // 1024 coefficients, 4 floats of padding per 32 (see post_rotate_transpose)
+#endif
 constexpr int kSlotCap = 96;
 constexpr int kFrameCap = 4352;          // >= 16 + 6+4+2+100+2*(4+2064), multiple of 16
 
@@ -365,6 +369,10 @@ __device__ __forceinline__ void fold(const int lane, const float (&ae)[CH][8], c
 
 // Post-rotation (mdct.rs:203-223) + transpose to the contiguous layout through LDS:
 //   out[2m] = -Z.re w.re - Z.im w.im,  out[1023 - 2m] = -Z.re w.im + Z.im w.re,   m = lane + 64 r
+// Coefficient k sits at dword k + 4 (k >> 5). A store instruction writes every other coefficient (2m, or 1023 - 2m), so
+// its 32 lanes of a bank group touch four blocks of 16 coefficients, 8 lanes each at a stride of two dwords: with the
+// blocks at bank offsets 0, 16, 4, 20 no bank is hit more than twice (free for ds_write_b32), where 4 floats of padding
+// per 16 put three lanes on the same bank. The 16-byte alignment the ds_read_b128 of the read side needs is kept.
 template <int CH>
 __device__ __forceinline__ void post_rotate_transpose(const int lane, const float (&zr)[CH][8], const float (&zi)[CH][8],
                                                       float (*coef)[kCoefFloats], float (&c)[CH][16],
@@ -375,7 +383,11 @@ __device__ __forceinline__ void post_rotate_transpose(const int lane, const floa
         const float4 t4 = T.pack[(8 + (r >> 1)) * 64 + lane];
         const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
         const int k0 = 2 * m, k1 = 1023 - 2 * m;
+#ifdef FLO_COEF_PAD16
         const int p0 = k0 + 4 * (k0 >> 4), p1 = k1 + 4 * (k1 >> 4);
+#else
+        const int p0 = k0 + 4 * (k0 >> 5), p1 = k1 + 4 * (k1 >> 5);
+#endif
 #pragma unroll
         for (int ch = 0; ch < CH; ch++) {
             float R = fmaf(-zi[ch][r], w.y, -(zr[ch][r] * w.x));
@@ -387,7 +399,11 @@ __device__ __forceinline__ void post_rotate_transpose(const int lane, const floa
     wave_sync();
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
+#ifdef FLO_COEF_PAD16
         const float4 *p = reinterpret_cast<const float4 *>(&coef[ch][20 * lane]);
+#else
+        const float4 *p = reinterpret_cast<const float4 *>(&coef[ch][16 * lane + 4 * (lane >> 1)]);
+#endif
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             float4 v = p[q];
@@ -396,6 +412,164 @@ __device__ __forceinline__ void post_rotate_transpose(const int lane, const floa
             c[ch][4 * q + 2] = v.z;
             c[ch][4 * q + 3] = v.w;
         }
+    }
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------ stereo in lock-step
+// The transform of BOTH channels of a stereo frame in one wave, the two channels as the halves of a float2: every
+// arithmetic instruction is a packed one (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, one issue slot for two channels;
+// constants are broadcast to both halves by the instruction's op_sel bits, negations are source modifiers), and the LDS
+// exchanges move 16 bytes per element (re0, re1, im0, im1). Each component goes through exactly the operations of the
+// single-channel functions above - same products, same fused multiply-adds, same order - so the coefficients are
+// bit-identical to theirs (the kernel forms are compared byte for byte by the tests).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
+
+constexpr int kXch4 = 64 * kXchStride;        // float4 elements of the stereo exchange buffer
+constexpr int kCoef2 = 1024 + 2 * 64;         // float2 elements: 16 coefficient pairs per lane, 2 elements of padding each
+
+__device__ __forceinline__ void dft8_2(v2f *xr, v2f *xi) {
+    const v2f s = splat2(0.70710678118654752440f);
+    v2f a0r = xr[0] + xr[4], a0i = xi[0] + xi[4];
+    v2f a1r = xr[0] - xr[4], a1i = xi[0] - xi[4];
+    v2f a2r = xr[2] + xr[6], a2i = xi[2] + xi[6];
+    v2f a3r = xr[2] - xr[6], a3i = xi[2] - xi[6];
+    v2f a4r = xr[1] + xr[5], a4i = xi[1] + xi[5];
+    v2f a5r = xr[1] - xr[5], a5i = xi[1] - xi[5];
+    v2f a6r = xr[3] + xr[7], a6i = xi[3] + xi[7];
+    v2f a7r = xr[3] - xr[7], a7i = xi[3] - xi[7];
+    v2f b0r = a0r + a2r, b0i = a0i + a2i;
+    v2f b2r = a0r - a2r, b2i = a0i - a2i;
+    v2f b1r = a1r + a3i, b1i = a1i - a3r;
+    v2f b3r = a1r - a3i, b3i = a1i + a3r;
+    v2f c0r = a4r + a6r, c0i = a4i + a6i;
+    v2f c2r = a4r - a6r, c2i = a4i - a6i;
+    v2f c1r = a5r + a7i, c1i = a5i - a7r;
+    v2f c3r = a5r - a7i, c3i = a5i + a7r;
+    const v2f e1r = c1r + c1i, e1i = c1i - c1r;
+    const v2f e3r = c3i - c3r, e3i = c3r + c3i;
+    xr[0] = b0r + c0r; xi[0] = b0i + c0i;
+    xr[4] = b0r - c0r; xi[4] = b0i - c0i;
+    xr[1] = fma2(e1r, s, b1r); xi[1] = fma2(e1i, s, b1i);
+    xr[5] = fma2(-e1r, s, b1r); xi[5] = fma2(-e1i, s, b1i);
+    xr[2] = b2r + c2i; xi[2] = b2i - c2r;
+    xr[6] = b2r - c2i; xi[6] = b2i + c2r;
+    xr[3] = fma2(e3r, s, b3r); xi[3] = fma2(-e3i, s, b3i);
+    xr[7] = fma2(-e3r, s, b3r); xi[7] = fma2(e3i, s, b3i);
+}
+
+__device__ __forceinline__ void cmul_2(v2f &xr, v2f &xi, float wr, float wi) {
+    const v2f WR = splat2(wr), WI = splat2(wi);
+    v2f r = fma2(xr, WR, -(xi * WI));
+    v2f i = fma2(xr, WI, xi * WR);
+    xr = r;
+    xi = i;
+}
+
+// fft512 for both channels; x4: kXch4 float4 elements (re0, re1, im0, im1), row stride kXchStride elements
+__device__ __forceinline__ void fft512_2(const int lane, v2f (&zr)[8], v2f (&zi)[8], float4 *x4, const LossyDevTables &T) {
+    dft8_2(zr, zi);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        const float4 w = T.pack[(12 + kk) * 64 + lane];
+        cmul_2(zr[2 * kk + 1], zi[2 * kk + 1], w.x, w.y);
+        if (kk < 3) cmul_2(zr[2 * kk + 2], zi[2 * kk + 2], w.z, w.w);
+    }
+    {
+        const int nb = lane >> 3, nc = lane & 7;
+#pragma unroll
+        for (int ka = 0; ka < 8; ka++) x4[(8 * ka + nc) * kXchStride + nb] = make_float4(zr[ka].x, zr[ka].y, zi[ka].x, zi[ka].y);
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const float4 v = x4[lane * kXchStride + r];
+            zr[r] = (v2f){v.x, v.y};
+            zi[r] = (v2f){v.z, v.w};
+        }
+        wave_sync();
+    }
+    dft8_2(zr, zi);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        const float4 w = T.pack[(16 + kk) * 64 + lane];
+        cmul_2(zr[2 * kk + 1], zi[2 * kk + 1], w.x, w.y);
+        if (kk < 3) cmul_2(zr[2 * kk + 2], zi[2 * kk + 2], w.z, w.w);
+    }
+    {
+        const int ka = lane >> 3, nc = lane & 7;
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) x4[(ka + 8 * kb) * kXchStride + nc] = make_float4(zr[kb].x, zr[kb].y, zi[kb].x, zi[kb].y);
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const float4 v = x4[lane * kXchStride + r];
+            zr[r] = (v2f){v.x, v.y};
+            zi[r] = (v2f){v.z, v.w};
+        }
+        wave_sync();
+    }
+    dft8_2(zr, zi);
+}
+
+// half-frame of a stereo clip as float2 loads: he[r] / ho[r] = (left, right) of the lane's even / odd sample of row r
+__device__ __forceinline__ void load_half_fast_2(const int lane, const float *__restrict__ pcm, long long s0, v2f (&he)[8], v2f (&ho)[8]) {
+    const char *base = reinterpret_cast<const char *>(pcm + s0 * 2);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int eo, oo;
+        half_offsets(lane, r, eo, oo);
+        const float2 a = *reinterpret_cast<const float2 *>(base + (unsigned)eo * 8u);
+        const float2 b = *reinterpret_cast<const float2 *>(base + (unsigned)oo * 8u);
+        he[r] = (v2f){a.x, a.y};
+        ho[r] = (v2f){b.x, b.y};
+    }
+}
+
+__device__ __forceinline__ void fold_2(const int lane, const v2f (&ae)[8], const v2f (&ao)[8], const v2f (&be)[8], const v2f (&bo)[8],
+                                       v2f (&zr)[8], v2f (&zi)[8], const LossyDevTables &T) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float4 ww = T.pack[r * 64 + lane];
+        const v2f wae = splat2(ww.x), wao = splat2(ww.y), wbe = splat2(ww.z), wbo = splat2(ww.w);
+        const float4 t4 = T.pack[(8 + (r >> 1)) * 64 + lane];
+        const v2f wx = splat2((r & 1) ? t4.z : t4.x), wy = splat2((r & 1) ? t4.w : t4.y);
+        v2f re, im;
+        if (r < 4) {
+            re = fma2(-bo[r], wbo, -(be[r] * wbe));
+            im = fma2(ao[r], wao, -(ae[r] * wae));
+        } else {
+            re = fma2(-ao[r], wao, ae[r] * wae);
+            im = fma2(-bo[r], wbo, -(be[r] * wbe));
+        }
+        zr[r] = fma2(-im, wy, -(re * wx));
+        zi[r] = fma2(re, wy, -(im * wx));
+    }
+}
+
+// post-rotation + transposition; c2: kCoef2 float2 elements, coefficient k of both channels at element k + 2 (k >> 4)
+__device__ __forceinline__ void post_rotate_transpose_2(const int lane, const v2f (&zr)[8], const v2f (&zi)[8], float2 *c2,
+                                                        v2f (&c)[16], const LossyDevTables &T) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int m = lane + 64 * r;
+        const float4 t4 = T.pack[(8 + (r >> 1)) * 64 + lane];
+        const v2f wx = splat2((r & 1) ? t4.z : t4.x), wy = splat2((r & 1) ? t4.w : t4.y);
+        const int k0 = 2 * m, k1 = 1023 - 2 * m;
+        const int p0 = k0 + 2 * (k0 >> 4), p1 = k1 + 2 * (k1 >> 4);
+        const v2f R = fma2(-zi[r], wy, -(zr[r] * wx));
+        const v2f I = fma2(zi[r], wx, -(zr[r] * wy));
+        c2[p0] = make_float2(R.x, R.y);
+        c2[p1] = make_float2(I.x, I.y);
+    }
+    wave_sync();
+    const float4 *p = reinterpret_cast<const float4 *>(&c2[18 * lane]);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const float4 v = p[q];
+        c[2 * q] = (v2f){v.x, v.y};
+        c[2 * q + 1] = (v2f){v.z, v.w};
     }
     wave_sync();
 }
@@ -637,6 +811,117 @@ __device__ __forceinline__ void quantise(const int lane, const float (&c)[CH][16
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stereo analysis
+// LDS of one lock-step transform wave. The exchange buffer, the transposition buffer and the band tables are live at
+// different times of a frame and share storage (a wave's LDS instructions execute in order, so the next use may be
+// issued as soon as the previous one's reads have been issued).
+constexpr int kSlots = kSlotCap + 64 + 1;
+struct StereoLds {
+    union {
+        float4 xch4[kXch4];
+        float2 coef2[kCoef2];
+        struct {
+            float2 sum[kSlots];   // per lane segment: (sum c^2 left, right) | 64 trash slots | zero slot
+            float2 mx[kSlots];    //                   (max |c| left, right)
+            float2 thr[32];       // per band: amplitude thresholds (left, right)
+            float2 sf[32];        // per band: scale factors
+        } a;
+    } u;
+};
+
+// band_stats for both channels: the sums are packed (one fused multiply-add per coefficient pair), the maxima are not
+// (there is no packed maximum). Same slots, same order of additions per channel as band_stats<CH>.
+__device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16], StereoLds &L, const LossyDevTables &T,
+                                             v2f &energy, v2f &bmax) {
+    char *sumb = reinterpret_cast<char *>(L.u.a.sum), *mxb = reinterpret_cast<char *>(L.u.a.mx);
+    if (lane == 0) {   // the zero slot shares storage with the exchange buffer: written every frame
+        L.u.a.sum[kZeroSlot] = make_float2(0.f, 0.f);
+        L.u.a.mx[kZeroSlot] = make_float2(0.f, 0.f);
+    }
+    v2f acc = splat2(0.f), mx = splat2(0.f);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const float4 keep = T.pack[(31 + g) * 64 + lane];
+        const float4 dsto = T.pack[(35 + g) * 64 + lane];
+        const float kp[4] = {keep.x, keep.y, keep.z, keep.w};
+        const uint32_t dv[4] = {__float_as_uint(dsto.x), __float_as_uint(dsto.y), __float_as_uint(dsto.z), __float_as_uint(dsto.w)};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = 4 * g + k;
+            acc = fma2(c[e], c[e], acc);
+            mx.x = max_abs_raw(mx.x, c[e].x);
+            mx.y = max_abs_raw(mx.y, c[e].y);
+            *reinterpret_cast<float2 *>(sumb + dv[k]) = make_float2(acc.x, acc.y);
+            *reinterpret_cast<float2 *>(mxb + dv[k]) = make_float2(mx.x, mx.y);
+            acc = acc * splat2(kp[k]);
+            mx = mx * splat2(kp[k]);
+        }
+    }
+    wave_sync();
+    energy = splat2(0.f);
+    bmax = splat2(0.f);
+    const int groups = (T.max_band_slots + 7) >> 3;
+    for (int g = 0; g < (groups < 3 ? 3 : groups); g++) {
+        const float4 lst = T.pack[(39 + g) * 64 + lane];
+        const uint32_t so[4] = {__float_as_uint(lst.x), __float_as_uint(lst.y), __float_as_uint(lst.z), __float_as_uint(lst.w)};
+        float2 vs[4], vm[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            vs[u] = *reinterpret_cast<const float2 *>(sumb + so[u]);
+            vm[u] = *reinterpret_cast<const float2 *>(mxb + so[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            energy = energy + (v2f){vs[u].x, vs[u].y};
+            bmax.x = max_raw(bmax.x, vm[u].x);
+            bmax.y = max_raw(bmax.y, vm[u].y);
+        }
+    }
+    energy.x += from_other_half(energy.x);
+    energy.y += from_other_half(energy.y);
+    bmax.x = max_raw(bmax.x, from_other_half(bmax.x));
+    bmax.y = max_raw(bmax.y, from_other_half(bmax.y));
+    wave_sync();
+}
+
+// quantise (shipped form: amplitude-domain keep test) for both channels, four coefficients at a time; the integers
+// leave as i16 pairs, element 2k in the low half of xs[ch][k] (the hand-over format of the packer wave)
+__device__ __forceinline__ void quantise_2(const int lane, const v2f (&c)[16], const StereoLds &L, const LossyDevTables &T,
+                                           uint32_t (&xs)[2][8]) {
+    const char *thrb = reinterpret_cast<const char *>(L.u.a.thr), *sfb = reinterpret_cast<const char *>(L.u.a.sf);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const float4 al4 = T.pack[(20 + g) * 64 + lane];
+        const float4 bo4 = T.pack[(27 + g) * 64 + lane];
+        const float al[4] = {al4.x, al4.y, al4.z, al4.w};
+        const uint32_t bo[4] = {__float_as_uint(bo4.x), __float_as_uint(bo4.y), __float_as_uint(bo4.z), __float_as_uint(bo4.w)};
+        float2 th[4], sf[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            th[k] = *reinterpret_cast<const float2 *>(thrb + bo[k]);
+            sf[k] = *reinterpret_cast<const float2 *>(sfb + bo[k]);
+        }
+        int v[2][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const v2f x = c[4 * g + k];
+            const v2f xsc = x * (v2f){sf[k].x, sf[k].y};
+            const v2f half = {__uint_as_float((__float_as_uint(xsc.x) & 0x80000000u) | 0x3EFFFFFFu),
+                              __uint_as_float((__float_as_uint(xsc.y) & 0x80000000u) | 0x3EFFFFFFu)};
+            const v2f rs = xsc + half;
+            const float t0 = max_raw(th[k].x, al[k]), t1 = max_raw(th[k].y, al[k]);
+            const int m0 = __float_as_int(t0 - fabsf(x.x)) >> 31, m1 = __float_as_int(t1 - fabsf(x.y)) >> 31;
+            v[0][k] = cvt_rz(rs.x) & m0;
+            v[1][k] = cvt_rz(rs.y) & m1;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            xs[ch][2 * g] = __builtin_amdgcn_perm((uint32_t)v[ch][1], (uint32_t)v[ch][0], 0x05040100u);
+            xs[ch][2 * g + 1] = __builtin_amdgcn_perm((uint32_t)v[ch][3], (uint32_t)v[ch][2], 0x05040100u);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ sparse RLE
 // Non-zero mask of the lane's 16 values (bit e = value e). An add-with-carry chain (compare sets the carry, v_addc
 // shifts it in: two instructions per value instead of three) was tried and lost: sixteen dependent steps.
@@ -805,6 +1090,160 @@ __device__ __forceinline__ void sparse_emit_n(const int lane, const int (&q)[CH]
         }
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------ sparse RLE, ballot form
+// The same serialize_sparse (encoder.rs:284-314) for the sparse frames that make up nearly all of a q <= 0.8 encode
+// (about 60 of 1024 values non-zero, 20 records), at a quarter of the vector instructions of the form above.
+//
+// Layout: lane l holds x[e] = value at position 64 e + l (zero-extended u16), so ONE compare per register gives 64
+// consecutive bits of the non-zero mask in a scalar register pair. Everything that describes the record structure is
+// then computed on the scalar unit from those sixteen ballots (run starts S = M & ~(M << 1), counts by s_bcnt1, the
+// first non-zero of a word by s_ff1): it costs no vector issue slots. What is left for the vector unit:
+//   value pass   per non-empty word: the value's byte offset = 2 (non-zeros before it + run starts at or before it)
+//                + (wide records so far) is four v_mbcnt with the word's ballots and one add-shift; active lanes store
+//                their two bytes. The run-start lanes also scatter (position, rank) into a small run table (LDS).
+//   header pass  one lane per RUN (64 at a time) reads its neighbours from the run table: zero run = gap to the previous
+//                run's end, count = difference of ranks, and stores [varint zero_run][count] in front of the run's values.
+// A zero run of 128 or more (two varint bytes) can only sit in front of the FIRST run start of a 64-bit word (runs of
+// zeros inside a word are shorter than 64), so the extra byte it inserts shifts a whole word's values uniformly: it is
+// a scalar term of the word's base address, and the header pass counts such records with one ballot.
+// Not handled here (the caller then takes the general form above, which overwrites whatever was written): a non-zero
+// run longer than 255 (continuation records), more runs than the run table holds. Both only occur in dense frames.
+constexpr int kRunTabEntries = 128;   // slot 0 and slot R + 1 are sentinels: up to 126 runs
+constexpr uint32_t kSparseFallback = 0xFFFFFFFFu;
+
+__device__ __forceinline__ void lds_st8_at(uint32_t a, uint32_t v, const int off) {
+    if (off == 0) asm volatile("ds_write_b8 %0, %1" ::"v"(a), "v"(v) : "memory");
+    else if (off == 1) asm volatile("ds_write_b8 %0, %1 offset:1" ::"v"(a), "v"(v) : "memory");
+    else if (off == 2) asm volatile("ds_write_b8 %0, %1 offset:2" ::"v"(a), "v"(v) : "memory");
+    else asm volatile("ds_write_b8 %0, %1 offset:3" ::"v"(a), "v"(v) : "memory");
+}
+// ds_write_b32 executed by the lanes of `mask` only (a wave-uniform mask, all lanes active on entry): the run-start
+// lanes are known as a scalar bit mask, and testing "my bit" on the vector unit would cost three instructions a word.
+__device__ __forceinline__ void lds_st32_lanes(unsigned long long mask, uint32_t a, uint32_t v) {
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv)
+                 : "s"(mask), "v"(a), "v"(v)
+                 : "memory");
+}
+
+// two byte stores (lo at a + OFF, hi at a + OFF + 1) executed by the lanes of `mask` only
+template <int OFF>
+__device__ __forceinline__ void lds_st8x2_lanes(unsigned long long mask, uint32_t a, uint32_t lo, uint32_t hi) {
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b8 %2, %3 offset:%5\n\tds_write_b8 %2, %4 offset:%6\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv)
+                 : "s"(mask), "v"(a), "v"(lo), "v"(hi), "n"(OFF), "n"(OFF + 1)
+                 : "memory");
+}
+
+// blob: LDS byte address of the channel's first sparse byte; tab: LDS byte address of kRunTabEntries dwords.
+// Returns the blob's length, or kSparseFallback.
+__device__ __forceinline__ uint32_t sparse_ballot_pack(const int lane, const uint32_t (&x)[16], const uint32_t blob,
+                                                       const uint32_t tab) {
+    unsigned long long bal[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) bal[e] = __ballot(x[e] != 0u);
+    uint32_t nM = 0, nS = 0, W = 0, cz = 0;   // non-zeros, run starts, wide records so far; zeros since the last non-zero
+    unsigned long long prevbit = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const unsigned long long b = bal[e];
+        if (b == 0ull) {   // uniform
+            cz += 64u;
+            prevbit = 0;
+            continue;
+        }
+        const uint32_t f = (uint32_t)__builtin_ctzll(b);
+        {
+            const uint32_t t7 = (cz + f) >> 7;   // zeros in front of the word's first run, in units of 128 (at most 8)
+            W += t7 < 1u ? t7 : 1u;
+        }
+        const unsigned long long S = b & ~((b << 1) | prevbit);
+        prevbit = b >> 63;
+        cz = (uint32_t)__builtin_clzll(b);
+        const uint32_t s0 = (uint32_t)S & 1u;
+        const unsigned long long U = S >> 1;
+        // v2 = non-zeros of this word below the lane; v4 - v2 = run starts of this word in lanes 1..lane
+        const uint32_t v2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        const uint32_t v4 = __builtin_amdgcn_mbcnt_hi((uint32_t)(U >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)U, v2));
+        const uint32_t H = blob + W;
+        const uint32_t K = nM + nS + s0 + (H >> 1);
+        const uint32_t a = (v4 + K) << 1;     // v_add_lshl_u32; the odd byte of H goes into the store's offset field
+        {
+            const uint32_t hi = x[e] >> 8;
+            if (H & 1u) lds_st8x2_lanes<1>(b, a, x[e], hi);   // uniform branch
+            else lds_st8x2_lanes<0>(b, a, x[e], hi);
+        }
+        // run table: slot = (runs before this word) + (starts of this word at or before the lane), slot 0 is a sentinel
+        {
+            const uint32_t sp = v4 - v2;
+            uint32_t ta = (sp << 2) + (tab + 4u * (nS + s0));
+            const uint32_t tmax = tab + 4u * (uint32_t)(kRunTabEntries - 1);
+            ta = ta < tmax ? ta : tmax;
+            const uint32_t ent = ((v2 << 16) + ((nM << 16) | (uint32_t)(64 * e))) | (uint32_t)lane;
+            lds_st32_lanes(S, ta, ent);
+        }
+        nM += (uint32_t)__builtin_popcountll(b);
+        nS += (uint32_t)__builtin_popcountll(S);
+    }
+    const uint32_t N = nM, R = nS;
+    if (R > (uint32_t)(kRunTabEntries - 2)) return kSparseFallback;
+    // sentinels: slot 0 = (position 0, rank 0); slot R + 1 = (rank N)
+    if (lane == 0) {
+        asm volatile("ds_write_b32 %0, %1" ::"v"(tab), "v"(0u) : "memory");
+        asm volatile("ds_write_b32 %0, %1" ::"v"(tab + 4u * (R + 1u)), "v"(N << 16) : "memory");
+    }
+    // header pass: one lane per run
+    uint32_t wdone = 0;   // wide records of the runs handled so far
+    bool too_long = false;
+    for (uint32_t j0 = 0; j0 < R; j0 += 64u) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        const bool act = j < R;
+        const uint32_t ja = tab + 4u * (act ? j : 0u);
+        uint32_t e0, e1, e2;
+        asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:4\n\tds_read_b32 %2, %3 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(e0), "=&v"(e1), "=&v"(e2)
+                     : "v"(ja)
+                     : "memory");
+        const uint32_t p0 = e0 & 0xFFFFu, r0 = e0 >> 16, p1 = e1 & 0xFFFFu, r1 = e1 >> 16, r2 = e2 >> 16;
+        const uint32_t cnt = r2 - r1;
+        const uint32_t zrun = p1 - (p0 + (r1 - r0));
+        const bool wide = act && zrun >= 128u;
+        const unsigned long long wb = __ballot(wide);
+        too_long |= __ballot(act && cnt > 255u) != 0ull;
+        uint32_t wex = wdone;
+        if (wb != 0ull) {   // uniform
+            wex += __builtin_amdgcn_mbcnt_hi((uint32_t)(wb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wb, 0u));
+            wdone += (uint32_t)__builtin_popcountll(wb);
+        }
+        const uint32_t ha = ((r1 + j) << 1) + (blob + wex);
+        if (act) {
+            lds_st8_at(ha, wide ? ((zrun & 0x7Fu) | 0x80u) : zrun, 0);
+            lds_st8_at(ha, wide ? (zrun >> 7) : cnt, 1);
+            if (wide) lds_st8_at(ha, cnt, 2);
+        }
+    }
+    if (too_long) return kSparseFallback;
+    // closing record of a trailing zero run: [varint zeros][0]  (cz = zeros behind the last non-zero, 1024 if none)
+    uint32_t tot = 2u * (N + R) + W;
+    if (cz != 0u) {
+        const uint32_t ta = blob + tot;
+        if (lane == 0) {
+            if (cz >= 128u) {
+                lds_st8_at(ta, (cz & 0x7Fu) | 0x80u, 0);
+                lds_st8_at(ta, cz >> 7, 1);
+                lds_st8_at(ta, 0u, 2);
+            } else {
+                lds_st8_at(ta, cz, 0);
+                lds_st8_at(ta, 0u, 1);
+            }
+        }
+        tot += cz >= 128u ? 3u : 2u;
+    }
+    return tot;
 }
 
 // single channel

@@ -11,6 +11,8 @@
 //                            re-runs the transform and finishes each frame into a fixed slot; compact_kernel
 //                            packs the slots. lossy_frame_n_kernel<P> is the same for 3 to 8 channels.
 //   All forms produce identical bytes (tests compare them file by file).
+#include <stdlib.h>
+
 #include "lossy_device.hpp"
 #include "lossy_kernels.hpp"
 #include "../../include/flo_synth.h"
@@ -20,6 +22,11 @@
 //   0 full | 1 no flush/barriers | 2 no emit | 3 no sparse plan | 4 no quantise | 5 no band stats/psy | 6 loads+fold only
 #ifndef FLO_ABLATE
 #define FLO_ABLATE 0
+#endif
+// FLO_ABLATE3=n (three-wave form): 1 packer does nothing | 2 + channel waves stop after the transform |
+//   3 + no post-rotation/transposition | 4 + no FFT (loads and fold only)
+#ifndef FLO_ABLATE3
+#define FLO_ABLATE3 0
 #endif
 #define FLO_KEEP(x) asm volatile("" ::"v"(x))
 // FLO_STAMPS (diagnostic builds only): s_memtime at phase boundaries of the chain kernel, summed per wave.
@@ -401,6 +408,7 @@ struct Clip3Lds {
     __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 256];
     __attribute__((aligned(16))) uint32_t qh[2][512];   // [channel][half * 64 + lane] uint4: eight i16 pairs... two uint4 per lane
     uint16_t sfwh[2][32];
+    uint32_t runtab[kRunTabEntries];   // run table of the ballot-form packer (one channel at a time)
     uint32_t ready[2];      // frames published by channel wave w
     uint32_t consumed;      // frames the packer has taken over
     uint32_t pad;
@@ -462,6 +470,7 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
     const unsigned hops = A.clip_hops[clip];
     const unsigned long long frame0 = A.clip_frame0[clip];
 
+#ifdef FLO_PACKER_GENERAL
     if (w == 2) {
         // ------------------------------------------------------------------ packer
         uint8_t *stage = cs.stage;
@@ -516,6 +525,111 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
         return;
     }
 
+#else
+    if (w == 2) {
+        // ------------------------------------------------------------------ packer
+        // Frame bytes (writer.rs:236-254 + encoder.rs:243-280) are composed in the staging buffer behind the < 16 bytes
+        // the previous frame left unflushed: [253][1024 u32][0][blob_len u32][0][2] | 2 x 25 scale words |
+        // per channel [len u32][sparse blob]. Each channel's blob comes from the ballot-form packer; a dense frame it
+        // declines goes through the general form (same bytes, tests compare them).
+        uint8_t *stage = cs.stage;
+        uint8_t *gout = A.out + A.out_off[clip];
+        unsigned long long written = 0;
+        uint32_t pend = 0, tailb = 0;
+        const uint32_t tab_a = (uint32_t)(uintptr_t)cs.runtab;
+        for (unsigned h = 0; h < hops; h++) {
+            const int ln = lane_id_opaque();
+            wait_counter(&cs.ready[0], h + 1);
+            wait_counter(&cs.ready[1], h + 1);
+            // hand-over buffer of a channel: value 16 l + k sits at halfword 8 l + k (k < 8) or 512 + 8 l + k - 8.
+            // Strided view for the ballot form: x[e] = value at position 64 e + lane.
+            uint32_t x[2][16], xs[2][8], sfw[2];
+            const uint32_t hw0 = 8u * ((uint32_t)ln >> 4) + ((uint32_t)ln & 7u) + 512u * (((uint32_t)ln >> 3) & 1u);
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                const uint16_t *hv = reinterpret_cast<const uint16_t *>(cs.qh[ch]);
+#pragma unroll
+                for (int e = 0; e < 16; e++) x[ch][e] = hv[hw0 + 32u * (uint32_t)e];
+                const uint4 *src = reinterpret_cast<const uint4 *>(cs.qh[ch]);
+                const uint4 x0 = src[ln], x1 = src[64 + ln];   // the lane's 16 contiguous values (general form only)
+                xs[ch][0] = x0.x, xs[ch][1] = x0.y, xs[ch][2] = x0.z, xs[ch][3] = x0.w;
+                xs[ch][4] = x1.x, xs[ch][5] = x1.y, xs[ch][6] = x1.z, xs[ch][7] = x1.w;
+                sfw[ch] = cs.sfwh[ch][ln & 31];
+            }
+            set_counter(&cs.consumed, h + 1);
+#if FLO_ABLATE3 >= 1
+            for (int e = 0; e < 16; e++) { FLO_KEEP(x[0][e]); FLO_KEEP(x[1][e]); }
+            for (int e = 0; e < 8; e++) { FLO_KEEP(xs[0][e]); FLO_KEEP(xs[1][e]); }
+            continue;
+#endif
+            // the < 16 bytes the previous frame left unflushed go back to the front of the staging buffer
+            if (ln < (int)pend) stage[ln] = (uint8_t)tailb;
+            uint8_t *f = stage + pend;
+            const uint32_t f_a = (uint32_t)(uintptr_t)f;
+            if (ln < 25) {
+#pragma unroll
+                for (int ch = 0; ch < 2; ch++) {
+                    uint8_t *p = f + 12 + 50 * ch + 2 * ln;
+                    lds_st8<0>(p, sfw[ch]);
+                    lds_st8<1>(p, sfw[ch] >> 8);
+                }
+            }
+            uint32_t tot[2];
+            uint32_t pos = 112;   // 12 + 50 * 2: length word of channel 0
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                uint32_t t = sparse_ballot_pack(ln, x[ch], f_a + pos + 4u, tab_a);
+                if (t == kSparseFallback) {   // uniform: dense frame (a run longer than 255, or more than 126 runs)
+                    int q[1][16];
+                    uint32_t hi[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        hi[k] = xs[ch][k] >> 16;
+                        q[0][2 * k] = (int)xs[ch][k];
+                        q[0][2 * k + 1] = (int)hi[k];
+                    }
+                    SparsePlan P[1];
+                    sparse_plan_m(ln, nonzero_mask16_packed(xs[ch], hi), P[0]);
+                    uint8_t *const dsts[1] = {f + pos + 4};
+                    // trash bytes of the general form: the tail of the staging buffer, two per lane
+                    const uint32_t trash[1] = {(uint32_t)((stage + kFrameCap + 64 + 2 * ln) - dsts[0])};
+                    sparse_emit_n<1>(ln, q, P, dsts, trash);
+                    t = P[0].total;
+                }
+                tot[ch] = t;
+                if (ln == 32 + ch) {
+                    uint8_t *p = f + pos;
+                    p[0] = (uint8_t)t; p[1] = (uint8_t)(t >> 8); p[2] = (uint8_t)(t >> 16); p[3] = (uint8_t)(t >> 24);
+                }
+                pos += 4u + t;
+            }
+            const uint32_t flen = pos, blob_len = flen - 10;
+            if (ln == 0) {
+                f[0] = 253;
+                f[1] = 0x00; f[2] = 0x04; f[3] = 0; f[4] = 0;  // frame_samples = 1024
+                f[5] = 0;
+                f[6] = (uint8_t)blob_len; f[7] = (uint8_t)(blob_len >> 8); f[8] = (uint8_t)(blob_len >> 16); f[9] = (uint8_t)(blob_len >> 24);
+                f[10] = 0;  // BlockSize::Long
+                f[11] = 2;
+                A.frame_size[frame0 + h] = flen;
+            }
+            wave_sync();
+            const uint32_t have = pend + flen;
+            const uint32_t n16 = have >> 4;
+            const uint4 *src = reinterpret_cast<const uint4 *>(stage);
+            uint4 *dst = reinterpret_cast<uint4 *>(gout + written);
+            for (uint32_t i = ln; i < n16; i += 64) dst[i] = src[i];
+            pend = have & 15u;
+            tailb = (ln < (int)pend) ? stage[(n16 << 4) + ln] : 0u;
+            written += (unsigned long long)n16 << 4;
+            wave_sync();
+        }
+        if (lane < (int)pend) gout[written + lane] = (uint8_t)tailb;
+        if (lane == 0) A.clip_bytes[clip] = written + pend;
+        return;
+    }
+
+#endif
     // ---------------------------------------------------------------------- channel waves
     WaveLds<1> &lds = cs.wl[w];
     if (lane == 0) lds.slots[0][kZeroSlot] = make_float2(0.f, 0.f);
@@ -546,10 +660,28 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
             float zr[1][8], zi[1][8];
             fold<1>(ln, pe, po, ce, co, zr, zi, T);
             load_half_fast<1>(ln, pcm, 2, w, (long long)(h + 1) * 1024, pe, po);   // unconditional: see lossy_chain_kernel
+#if FLO_ABLATE3 >= 4
+            for (int r = 0; r < 8; r++) { FLO_KEEP(zr[0][r]); FLO_KEEP(zi[0][r]); }
+            wait_counter(&cs.consumed, h);
+            set_counter(&cs.ready[w], h + 1);
+            return;
+#endif
             fft512<1>(ln, zr, zi, lds.u.xch, T);
+#if FLO_ABLATE3 >= 3
+            for (int r = 0; r < 8; r++) { FLO_KEEP(zr[0][r]); FLO_KEEP(zi[0][r]); }
+            wait_counter(&cs.consumed, h);
+            set_counter(&cs.ready[w], h + 1);
+            return;
+#endif
             post_rotate_transpose<1>(ln, zr, zi, lds.u.coef, c, T);
             store_coeffs_dbg<1>(ln, c, A, frame0 + h, w);
         }
+#if FLO_ABLATE3 >= 2
+        for (int e = 0; e < 16; e++) FLO_KEEP(c[0][e]);
+        wait_counter(&cs.consumed, h);
+        set_counter(&cs.ready[w], h + 1);
+        return;
+#endif
         int q[1][16];
         uint32_t sfw[1];
         SparsePlan P[1];
@@ -573,6 +705,268 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
         frame_body(h, ae, ao, be, bo);
         if (h + 1 < hops) frame_body(h + 1, be, bo, ae, ao);
     }
+}
+
+// ---------------------------------------------------------------------------------------------- two waves per clip
+// Stereo clips, one TRANSFORM wave per clip that carries both channels in lock-step + the packer wave: every constant
+// row (window, twiddles, band tables) is read from LDS once per frame for both channels, the PCM comes in as float2
+// loads (both channels of a sample-frame), and the two channels are two independent dependency chains inside one
+// instruction stream, so a wait on LDS is shared by twice the work. Same device functions, same bytes as the other forms.
+struct Clip2xLds {
+    StereoLds wl;
+    __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 256];
+    __attribute__((aligned(16))) uint32_t qh[2][512];
+    uint16_t sfwh[2][32];
+    uint32_t runtab[kRunTabEntries];
+    uint32_t ready[2];      // frames published (both entries move together: the packer code is shared with the three-wave form)
+    uint32_t consumed;
+    uint32_t clip_seq;      // clips handed to the transform wave so far ...
+    uint32_t clip_cur;      // ... and the latest one
+    uint32_t pad[3];
+};
+static_assert(sizeof(Clip2xLds) % 16 == 0, "clip LDS block keeps 16-byte alignment");
+
+#ifndef FLO_C2X_THREADS
+#define FLO_C2X_THREADS 768
+#endif
+template <bool EXACT>
+__global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArgs A, int clips_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    {
+        float4 *dstp = reinterpret_cast<float4 *>(lds_raw);
+        for (int i = tid; i < kPackRows * 64; i += (int)blockDim.x) dstp[i] = A.T.pack[i];
+        for (int i = tid; i < clips_per_wg; i += (int)blockDim.x) {
+            Clip2xLds &c0 = *reinterpret_cast<Clip2xLds *>(lds_raw + kPackBytes + (size_t)i * sizeof(Clip2xLds));
+            c0.ready[0] = 0;
+            c0.ready[1] = 0;
+            c0.consumed = 0;
+            c0.clip_seq = 0;
+        }
+    }
+    __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // waves 0 .. g-1 are the transform waves (one per SIMD first), waves g .. 2g-1 the packers
+    const int cl = wv % clips_per_wg;
+    const int w = wv < clips_per_wg ? 0 : 2;
+    Clip2xLds &cs = *reinterpret_cast<Clip2xLds *>(lds_raw + kPackBytes + (size_t)cl * sizeof(Clip2xLds));
+    // Clips are dealt dynamically: the workgroups are persistent (one per CU, the LDS holds no second one) and every
+    // (transform wave, packer wave) pair takes the next unclaimed clip of the batch when it has finished one, so CUs
+    // stay full until the batch runs out whatever the clip lengths. The packer claims (one atomic per clip) and tells
+    // its transform wave through LDS; frame counters run on across clips (fbase), so nothing is ever reset.
+    uint32_t fbase = 0, seq = 0;
+    for (;;) {
+    unsigned clip;
+    if (w == 2) {
+        unsigned got = 0;
+        if (lane == 0) got = atomicAdd(A.next_clip, 1u);
+        clip = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+        if (lane == 0) cs.clip_cur = clip;
+        set_counter(&cs.clip_seq, ++seq);
+    } else {
+        wait_counter(&cs.clip_seq, ++seq);
+        clip = (unsigned)__builtin_amdgcn_readfirstlane((int)cs.clip_cur);
+    }
+    if (clip >= (unsigned)A.n_clips) return;
+    const unsigned hops = A.clip_hops[clip];
+    const unsigned long long frame0 = A.clip_frame0[clip];
+
+    if (w == 2) {
+        // ------------------------------------------------------------------ packer
+        // Frame bytes (writer.rs:236-254 + encoder.rs:243-280) are composed in the staging buffer behind the < 16 bytes
+        // the previous frame left unflushed: [253][1024 u32][0][blob_len u32][0][2] | 2 x 25 scale words |
+        // per channel [len u32][sparse blob]. Each channel's blob comes from the ballot-form packer; a dense frame it
+        // declines goes through the general form (same bytes, tests compare them).
+        uint8_t *stage = cs.stage;
+        uint8_t *gout = A.out + A.out_off[clip];
+        unsigned long long written = 0;
+        uint32_t pend = 0, tailb = 0;
+        const uint32_t tab_a = (uint32_t)(uintptr_t)cs.runtab;
+        for (unsigned h = 0; h < hops; h++) {
+            const int ln = lane_id_opaque();
+            wait_counter(&cs.ready[0], fbase + h + 1);
+            wait_counter(&cs.ready[1], fbase + h + 1);
+            // hand-over buffer of a channel: value 16 l + k sits at halfword 8 l + k (k < 8) or 512 + 8 l + k - 8.
+            // Strided view for the ballot form: x[e] = value at position 64 e + lane.
+            uint32_t x[2][16], xs[2][8];
+            const uint32_t hw0 = 8u * ((uint32_t)ln >> 4) + ((uint32_t)ln & 7u) + 512u * (((uint32_t)ln >> 3) & 1u);
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                const uint16_t *hv = reinterpret_cast<const uint16_t *>(cs.qh[ch]);
+#pragma unroll
+                for (int e = 0; e < 16; e++) x[ch][e] = hv[hw0 + 32u * (uint32_t)e];
+                const uint4 *src = reinterpret_cast<const uint4 *>(cs.qh[ch]);
+                const uint4 x0 = src[ln], x1 = src[64 + ln];   // the lane's 16 contiguous values (general form only)
+                xs[ch][0] = x0.x, xs[ch][1] = x0.y, xs[ch][2] = x0.z, xs[ch][3] = x0.w;
+                xs[ch][4] = x1.x, xs[ch][5] = x1.y, xs[ch][6] = x1.z, xs[ch][7] = x1.w;
+            }
+            const uint32_t sfw_both = cs.sfwh[ln >> 5][ln & 31];   // scale words: lanes 0..24 left, 32..56 right
+            set_counter(&cs.consumed, fbase + h + 1);
+#if FLO_ABLATE3 >= 1
+            for (int e = 0; e < 16; e++) { FLO_KEEP(x[0][e]); FLO_KEEP(x[1][e]); }
+            for (int e = 0; e < 8; e++) { FLO_KEEP(xs[0][e]); FLO_KEEP(xs[1][e]); }
+            continue;
+#endif
+            // the < 16 bytes the previous frame left unflushed go back to the front of the staging buffer
+            if (ln < (int)pend) stage[ln] = (uint8_t)tailb;
+            uint8_t *f = stage + pend;
+            const uint32_t f_a = (uint32_t)(uintptr_t)f;
+            if ((ln & 31) < 25) {
+                uint8_t *p = f + 12 + 50 * (ln >> 5) + 2 * (ln & 31);
+                lds_st8<0>(p, sfw_both);
+                lds_st8<1>(p, sfw_both >> 8);
+            }
+            uint32_t tot[2];
+            uint32_t pos = 112;   // 12 + 50 * 2: length word of channel 0
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                uint32_t t = sparse_ballot_pack(ln, x[ch], f_a + pos + 4u, tab_a);
+                if (t == kSparseFallback) {   // uniform: dense frame (a run longer than 255, or more than 126 runs)
+                    int q[1][16];
+                    uint32_t hi[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        hi[k] = xs[ch][k] >> 16;
+                        q[0][2 * k] = (int)xs[ch][k];
+                        q[0][2 * k + 1] = (int)hi[k];
+                    }
+                    SparsePlan P[1];
+                    sparse_plan_m(ln, nonzero_mask16_packed(xs[ch], hi), P[0]);
+                    uint8_t *const dsts[1] = {f + pos + 4};
+                    // trash bytes of the general form: the tail of the staging buffer, two per lane
+                    const uint32_t trash[1] = {(uint32_t)((stage + kFrameCap + 64 + 2 * ln) - dsts[0])};
+                    sparse_emit_n<1>(ln, q, P, dsts, trash);
+                    t = P[0].total;
+                }
+                tot[ch] = t;
+                if (ln == 32 + ch) {
+                    uint8_t *p = f + pos;
+                    p[0] = (uint8_t)t; p[1] = (uint8_t)(t >> 8); p[2] = (uint8_t)(t >> 16); p[3] = (uint8_t)(t >> 24);
+                }
+                pos += 4u + t;
+            }
+            const uint32_t flen = pos, blob_len = flen - 10;
+            if (ln == 0) {
+                f[0] = 253;
+                f[1] = 0x00; f[2] = 0x04; f[3] = 0; f[4] = 0;  // frame_samples = 1024
+                f[5] = 0;
+                f[6] = (uint8_t)blob_len; f[7] = (uint8_t)(blob_len >> 8); f[8] = (uint8_t)(blob_len >> 16); f[9] = (uint8_t)(blob_len >> 24);
+                f[10] = 0;  // BlockSize::Long
+                f[11] = 2;
+                A.frame_size[frame0 + h] = flen;
+            }
+            wave_sync();
+            const uint32_t have = pend + flen;
+            const uint32_t n16 = have >> 4;
+            const uint4 *src = reinterpret_cast<const uint4 *>(stage);
+            uint4 *dst = reinterpret_cast<uint4 *>(gout + written);
+            for (uint32_t i = ln; i < n16; i += 64) dst[i] = src[i];
+            pend = have & 15u;
+            tailb = (ln < (int)pend) ? stage[(n16 << 4) + ln] : 0u;
+            written += (unsigned long long)n16 << 4;
+            wave_sync();
+        }
+        if (lane < (int)pend) gout[written + lane] = (uint8_t)tailb;
+        if (lane == 0) A.clip_bytes[clip] = written + pend;
+        fbase += hops;
+        continue;
+    }
+
+
+    // ---------------------------------------------------------------------- transform wave: both channels
+    StereoLds &lds = cs.wl;
+    LossyDevTables T = A.T;
+    T.pack = reinterpret_cast<const float4 *>(lds_raw);
+    const float *pcm = A.pcm + A.clip_off[clip];
+
+    float prev[2] = {0.f, 0.f};   // lanes 0..24: temporal masking state of band `lane`, per channel
+    v2f ae[8], ao[8], be[8], bo[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) ae[r] = ao[r] = splat2(0.f);  // pre-roll: 1024 zeros (encoder.rs:177)
+    if (!A.in_coeffs) load_half_fast_2(lane_id_opaque(), pcm, 0, be, bo);   // (opaque: keeps 16 address pairs out of loop-invariant registers)
+    auto frame_body = [&](const unsigned h, v2f (&pe)[8], v2f (&po)[8], v2f (&ce)[8], v2f (&co)[8]) __attribute__((always_inline)) {
+        const int ln = lane_id_opaque();
+        v2f c[16];
+        if (A.in_coeffs) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 v0 = reinterpret_cast<const float4 *>(A.in_coeffs + ((frame0 + h) * 2 + 0) * 1024 + 16 * ln)[q];
+                const float4 v1 = reinterpret_cast<const float4 *>(A.in_coeffs + ((frame0 + h) * 2 + 1) * 1024 + 16 * ln)[q];
+                c[4 * q] = (v2f){v0.x, v1.x}; c[4 * q + 1] = (v2f){v0.y, v1.y};
+                c[4 * q + 2] = (v2f){v0.z, v1.z}; c[4 * q + 3] = (v2f){v0.w, v1.w};
+            }
+        } else {
+            v2f zr[8], zi[8];
+            fold_2(ln, pe, po, ce, co, zr, zi, T);
+            // the older half is dead after the fold: the half-frame after next is loaded into its registers now and
+            // consumed at the top of the next call. Unconditional, also behind the last frame (the batch allocates one
+            // spare half-frame per clip): see lossy_chain_kernel
+            load_half_fast_2(ln, pcm, (long long)(h + 1) * 1024, pe, po);
+            fft512_2(ln, zr, zi, lds.u.xch4, T);
+            post_rotate_transpose_2(ln, zr, zi, lds.u.coef2, c, T);
+
+            if (A.dbg_coeffs) {
+#pragma unroll
+                for (int ch = 0; ch < 2; ch++) {
+                    float *d = A.dbg_coeffs + ((frame0 + h) * 2 + ch) * 1024 + 16 * ln;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) d[e] = ch ? c[e].y : c[e].x;
+                }
+            }
+        }
+        // band statistics, masking level, temporal masking, scale factors (analyse_frame, both channels)
+        v2f energy, bmax;
+        band_stats_2(ln, c, lds, T, energy, bmax);
+        const float rcount = T.pack[26 * 64 + ln].z;
+        uint32_t sfw[2];
+        float tl[2], sfv[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            const float a = spread_threshold(ln, ch ? energy.y : energy.x, rcount, T);
+            const float sl = max_raw(a, prev[ch] * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
+            prev[ch] = sl;
+            tl[ch] = masking_amplitude(sl, T.smr_thr);
+            const float bm = ch ? bmax.y : bmax.x;
+            sfv[ch] = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
+            sfw[ch] = sf_word(sfv[ch]);
+        }
+        if (ln < 25) {
+            lds.u.a.thr[ln] = make_float2(tl[0], tl[1]);
+            lds.u.a.sf[ln] = make_float2(sfv[0], sfv[1]);
+        }
+        wave_sync();
+        uint32_t xs[2][8];
+        quantise_2(ln, c, lds, T, xs);
+        if (A.dbg_q) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                uint32_t *dq = reinterpret_cast<uint32_t *>(A.dbg_q + ((frame0 + h) * 2 + ch) * 1024 + 16 * ln);
+#pragma unroll
+                for (int k = 0; k < 8; k++) dq[k] = xs[ch][k];
+            }
+        }
+        if (A.dbg_sfw && ln < 25) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) A.dbg_sfw[((frame0 + h) * 2 + ch) * 25 + ln] = (unsigned short)sfw[ch];
+        }
+        wait_counter(&cs.consumed, fbase + h);   // the packer has taken the previous frame out of the hand-over buffer
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            uint4 *dq = reinterpret_cast<uint4 *>(cs.qh[ch]);
+            dq[ln] = make_uint4(xs[ch][0], xs[ch][1], xs[ch][2], xs[ch][3]);
+            dq[64 + ln] = make_uint4(xs[ch][4], xs[ch][5], xs[ch][6], xs[ch][7]);
+            if (ln < 25) cs.sfwh[ch][ln] = (uint16_t)sfw[ch];
+        }
+        set_counter(&cs.ready[0], fbase + h + 1);
+        set_counter(&cs.ready[1], fbase + h + 1);
+    };
+    for (unsigned h = 0; h < hops; h += 2) {
+        frame_body(h, ae, ao, be, bo);
+        if (h + 1 < hops) frame_body(h + 1, be, bo, ae, ao);
+    }
+    fbase += hops;
+    }   // next clip
 }
 
 // ---------------------------------------------------------------------------------------------- frame-parallel
@@ -814,22 +1208,33 @@ __global__ __launch_bounds__(64) void mdct_only_kernel(LossyDevTables T, const f
     for (int q = 0; q < 4; q++) d[q] = make_float4(c[0][4 * q], c[0][4 * q + 1], c[0][4 * q + 2], c[0][4 * q + 3]);
 }
 
-// serialize_sparse of independent 1024-value vectors into fixed slots (flo_sparse_pack)
+// serialize_sparse of independent 1024-value vectors into fixed slots (flo_sparse_pack): the packer wave's own
+// routine, i.e. the ballot form with the general form behind it for the vectors it declines. form = 1 forces the
+// general form for every vector (tests compare the two).
 __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigned long long n, uint8_t *slots,
-                                                         uint32_t *sizes) {
+                                                         uint32_t *sizes, int form) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[2080 + 128];
+    __shared__ uint32_t runtab[kRunTabEntries];
     const unsigned long long w = blockIdx.x;
     if (w >= n) return;
     const int lane = lane_id();
-    int v[16];
+    const unsigned short *qv = reinterpret_cast<const unsigned short *>(q) + w * 1024;
+    uint32_t x[16];
 #pragma unroll
-    for (int e = 0; e < 16; e++) v[e] = q[w * 1024 + 16 * lane + e];
-    SparsePlan P;
-    sparse_plan(lane, v, P);
-    sparse_emit(lane, v, P, stage, 2080u + 2u * (uint32_t)lane);
+    for (int e = 0; e < 16; e++) x[e] = qv[64 * e + lane];
+    uint32_t total = form == 1 ? kSparseFallback : sparse_ballot_pack(lane, x, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab);
+    if (total == kSparseFallback) {
+        int v[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) v[e] = q[w * 1024 + 16 * lane + e];
+        SparsePlan P;
+        sparse_plan(lane, v, P);
+        sparse_emit(lane, v, P, stage, 2080u + 2u * (uint32_t)lane);
+        total = P.total;
+    }
     wave_sync();
-    for (uint32_t i = lane; i < P.total; i += 64) slots[w * 2080 + i] = stage[i];
-    if (lane == 0) sizes[w] = P.total;
+    for (uint32_t i = lane; i < total; i += 64) slots[w * 2080 + i] = stage[i];
+    if (lane == 0) sizes[w] = total;
 }
 
 // Copy every clip's DATA chunk or finished file into one caller-provided buffer, back to back at 16-byte aligned
@@ -954,6 +1359,40 @@ static int launch_chain3_t(const LossyArgs &A, hipStream_t s) {
     FLO_LAUNCH_CHECK();
     return 0;
 }
+// clips per workgroup of the two-wave (lock-step stereo) form
+int chain2x_clips_per_wg(int n_clips) {
+    int g = (n_clips + 255) / 256;
+    const int gmax = (int)((160 * 1024 - kPackBytes) / sizeof(Clip2xLds));
+    if (g > gmax) g = gmax;
+    if (g > FLO_C2X_THREADS / 128) g = FLO_C2X_THREADS / 128;   // twelve waves: three per SIMD (up to 168 registers each)
+    return g < 1 ? 1 : g;
+}
+template <bool EXACT>
+static int launch_chain2x_t(const LossyArgs &A, hipStream_t s) {
+    int g = chain2x_clips_per_wg(A.n_clips);
+    if (const char *e = getenv("FLO_CHAIN2X_CLIPS")) {   // diagnostic: clips per workgroup
+        const int v = atoi(e);
+        if (v >= 1 && v <= FLO_C2X_THREADS / 128) g = v;
+    }
+    const size_t lds = kPackBytes + (size_t)g * sizeof(Clip2xLds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lossy_chain2x_kernel<EXACT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    unsigned wgs = (unsigned)((A.n_clips + g - 1) / g);
+    if (A.n_cus > 0 && wgs > (unsigned)A.n_cus) wgs = (unsigned)A.n_cus;   // persistent: one workgroup per CU, clips dealt dynamically
+    hipLaunchKernelGGL((lossy_chain2x_kernel<EXACT>), dim3(wgs), dim3(128 * g), lds, s, A, g);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_lossy_chain2x(const LossyArgs &A, hipStream_t s) {
+    if (A.nch != 2 || A.exact) return -1;   // the exact-threshold test yardstick lives in the other forms
+    return launch_chain2x_t<false>(A, s);
+}
+
 int launch_lossy_chain3(const LossyArgs &A, hipStream_t s) {
     if (A.nch != 2) return -1;
     return A.exact ? launch_chain3_t<true>(A, s) : launch_chain3_t<false>(A, s);
@@ -1001,8 +1440,8 @@ int launch_mdct_only(const LossyDevTables &T, const float *frames, unsigned long
     FLO_LAUNCH_CHECK();
     return 0;
 }
-int launch_sparse_only(const short *q, unsigned long long n, uint8_t *slots, uint32_t *sizes, hipStream_t s) {
-    hipLaunchKernelGGL(sparse_only_kernel, dim3((unsigned)n), dim3(64), 0, s, q, n, slots, sizes);
+int launch_sparse_only(const short *q, unsigned long long n, uint8_t *slots, uint32_t *sizes, int form, hipStream_t s) {
+    hipLaunchKernelGGL(sparse_only_kernel, dim3((unsigned)n), dim3(64), 0, s, q, n, slots, sizes, form);
     FLO_LAUNCH_CHECK();
     return 0;
 }

@@ -38,10 +38,13 @@ struct LossyArgs {
     const float *in_coeffs;                  // when set: skip the transform, quantise these spectra
     unsigned long long *dbg_stamps;          // diagnostic builds (FLO_STAMPS): per-wave phase cycle sums [wave][16]
     int exact;                               // re-decide near-threshold coefficients with the reference's dB expression
+    unsigned int *next_clip;                 // lock-step stereo form: batch-wide counter of claimed clips (zero at launch)
+    int n_cus;                               // compute units of the device (persistent workgroups)
 };
 
 int launch_lossy_chain(const LossyArgs &A, hipStream_t s);
-int launch_lossy_chain3(const LossyArgs &A, hipStream_t s);   // stereo only: two channel waves + one packer wave per clip
+int launch_lossy_chain3(const LossyArgs &A, hipStream_t s);
+int launch_lossy_chain2x(const LossyArgs &A, hipStream_t s);  // stereo only: one lock-step transform wave + one packer wave per clip   // stereo only: two channel waves + one packer wave per clip
 int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s);
 // bytes reserved per frame in the frame-parallel form: header + scale words + every channel's largest sparse blob
 inline unsigned int lossy_slot_bytes(int nch) {
@@ -53,7 +56,7 @@ constexpr int kMaxLossyChannels = 8;      // more channels than two take the gen
 int launch_lossy_scan(const LossyArgs &A, hipStream_t s);
 int launch_lossy_compact(const LossyArgs &A, hipStream_t s);
 int launch_mdct_only(const LossyDevTables &T, const float *frames, unsigned long long n, float *out, hipStream_t s);
-int launch_sparse_only(const short *q, unsigned long long n, uint8_t *slots, uint32_t *sizes, hipStream_t s);
+int launch_sparse_only(const short *q, unsigned long long n, uint8_t *slots, uint32_t *sizes, int form, hipStream_t s);
 int launch_pack_streams(const uint8_t *src, const unsigned long long *src_off, const unsigned long long *dst_off,
                         const unsigned long long *sizes, int n_clips, uint8_t *dst, hipStream_t s);
 int launch_synth_fill(float *pcm, const unsigned long long *clip_off, const unsigned long long *clip_nsf, int n_clips,

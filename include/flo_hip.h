@@ -111,7 +111,9 @@ int flo_batch_upload(flo_batch *b, size_t clip, const float *pcm);
 int flo_batch_fill_synthetic(flo_batch *b, uint32_t seed, uint64_t clip_id0);
 /* launch the encode kernels on the ctx stream (asynchronous). which = 0: auto, 1: clip-chain kernel with one wave
  * per channel, 2: frame-parallel kernels, 3: clip-chain kernel with two channel waves + one packer wave per stereo
- * clip (lossy only; all forms produce identical bytes) */
+ * clip, 4: clip-chain kernel with one transform wave that carries both channels in lock-step (packed f32 arithmetic)
+ * + one packer wave per stereo clip, persistent workgroups that deal the clips dynamically: the form auto picks for
+ * stereo batches (lossy only; all forms produce identical bytes; 3 and 4 fall back to 1 for mono) */
 int flo_batch_encode(flo_batch *b, int which);
 int flo_batch_sync(flo_batch *b);
 /* after sync: total compressed DATA bytes of the batch, and of one clip */
@@ -144,8 +146,7 @@ int flo_ctx_profile_enable(flo_ctx *ctx, int on);
 /* sum and count of bracketed launches of `kernel` since the last reset (call after a sync) */
 int flo_ctx_profile_query(flo_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 int flo_ctx_profile_reset(flo_ctx *ctx);
-/* test hook: force the lossy kernel form (0 auto, 1 chain with one wave per channel, 2 frame-parallel,
- * 3 chain with two channel waves + one packer wave per stereo clip; 3 falls back to 1 for mono) */
+/* test hook: force the lossy kernel form (0 auto, 1 .. 4 as in flo_batch_encode) */
 int flo_ctx_force_path(flo_ctx *ctx, int which);
 /* stream handle (hipStream_t) of the context, for callers that enqueue their own work around the encode */
 void *flo_ctx_stream(flo_ctx *ctx);
@@ -168,8 +169,10 @@ int flo_lossy_analyze(flo_ctx *ctx, const float *pcm, size_t n_interleaved, uint
 int flo_lossy_quantize(flo_ctx *ctx, const float *coeffs, size_t num_hops, uint32_t sample_rate, uint8_t channels,
                        float quality, int exact, int16_t *quantized, uint16_t *sf_words);
 /* serialize_sparse on device: n_vec vectors of 1024 i16 -> bytes; out_off[n_vec+1] prefix offsets.
- * Replaces lossy/encoder.rs:284-314 */
-int flo_sparse_pack(flo_ctx *ctx, const int16_t *q, size_t n_vec, uint8_t *out, size_t out_cap, uint32_t *out_off);
+ * Replaces lossy/encoder.rs:284-314. form = 0: the packer as the encoder runs it (ballot form for sparse vectors, the
+ * general form for the dense ones it declines); form = 1: the general form for every vector (tests compare the two). */
+int flo_sparse_pack(flo_ctx *ctx, const int16_t *q, size_t n_vec, int form, uint8_t *out, size_t out_cap,
+                    uint32_t *out_off);
 
 #ifdef __cplusplus
 }

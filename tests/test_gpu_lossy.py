@@ -55,11 +55,60 @@ def _patterns():
     return np.array(pats)
 
 
-def test_sparse_pack_bit_exact(ctx):
+@pytest.mark.parametrize("form", [0, 1], ids=["encoder", "general"])
+def test_sparse_pack_bit_exact(ctx, form):
+    # form 0 = the packer as every encode runs it (ballot form, the general form behind it for dense vectors)
     pats = _patterns()
-    got = ctx.sparse_pack(pats)
+    got = ctx.sparse_pack(pats, form)
     for i, p in enumerate(pats):
         assert got[i] == O.serialize_sparse(p), i
+
+
+def test_sparse_pack_ballot_form_on_structured_vectors(ctx):
+    # what the ballot form has to get right: zero runs of 127 / 128 / 129 and longer in front of a word's first run
+    # (two-byte varints shift everything behind them by one byte), runs that cross 64-bit word boundaries, runs of
+    # exactly 255 and 256, up to 126 and 127 runs (run table capacity), trailing zero runs of every varint size
+    rng = np.random.default_rng(5)
+    pats = []
+    for gap in (1, 63, 64, 65, 126, 127, 128, 129, 191, 192, 193, 255, 256, 300, 511, 640, 1000):
+        for first in (0, 1, 5, 63, 64, 100):
+            a = np.zeros(1024, np.int16)
+            pos, k = first, 0
+            while pos < 1024:
+                n = int(rng.integers(1, 5))
+                a[pos:pos + n] = rng.integers(1, 30000, min(n, 1024 - pos)) * rng.choice([-1, 1])
+                pos += n + gap + (k % 3 == 0)
+                k += 1
+            pats.append(a)
+    for run in (62, 63, 64, 65, 127, 128, 129, 190, 191, 192, 193, 254, 255, 256, 257, 300):
+        for start in (0, 1, 31, 63, 64, 65, 700):
+            a = np.zeros(1024, np.int16)
+            a[start:start + run] = -7
+            a[min(1023, start + run + 130)] = 9
+            pats.append(a)
+    for runs in (1, 2, 63, 64, 65, 125, 126, 127, 128, 200, 512):
+        a = np.zeros(1024, np.int16)
+        a[0:2 * runs:2] = 3
+        pats.append(a)
+        b = np.zeros(1024, np.int16)
+        b[1:2 * runs:2][:runs] = -3
+        pats.append(b)
+    for tail in (0, 1, 2, 127, 128, 129, 500, 1023):
+        a = np.full(1024, 11, np.int16)
+        a[::7] = 0
+        if tail:
+            a[1024 - tail:] = 0
+        pats.append(a)
+    for dens in (0.01, 0.03, 0.06, 0.12, 0.25):
+        for _ in range(40):
+            keep = rng.uniform(size=1024) < dens * np.exp(-np.arange(1024) / rng.uniform(100, 900))   # low-pass like a spectrum
+            pats.append((rng.integers(-32768, 32768, 1024) * keep).astype(np.int16))
+    pats = np.array(pats)
+    got0, got1 = ctx.sparse_pack(pats, 0), ctx.sparse_pack(pats, 1)
+    for i, p in enumerate(pats):
+        ref = O.serialize_sparse(p)
+        assert got0[i] == ref, i
+        assert got1[i] == ref, i
 
 
 @pytest.mark.parametrize("exact", [False, True], ids=["shipped", "exact"])
@@ -130,17 +179,28 @@ def test_kept_integers_are_no_further_from_an_exact_transform_than_the_oracle(ct
 def test_analyze_parity(ctx, ch, q):
     pcm = signals.music_like(44100, 40000, ch, seed=10 + ch)
     o = O.lossy_analyze(pcm, 44100, ch, q)
-    for path in (1, 2):
+    first = None
+    for path in (1, 2, 3, 4):      # 3 and 4 are stereo forms (mono falls back to 1)
         ctx.force_path(path)
         g = ctx.lossy_analyze(pcm, 44100, ch, q)
         compare_lossy_stage(g, o, 44100, tag=f"path{path}")
+        # every form computes the same coefficients, integers and scale words, bit for bit
+        if first is None:
+            first = g
+        else:
+            for key in ("coeffs", "q", "sf_words"):
+                assert np.array_equal(first[key].view(np.uint8), g[key].view(np.uint8)), (path, key)
     ctx.force_path(0)
 
 
 @pytest.mark.parametrize("sr", [8000, 22050, 48000, 96000])
 def test_other_sample_rates(ctx, sr):
     pcm = signals.music_like(sr, 20000, 2, seed=sr)
-    compare_lossy_stage(ctx.lossy_analyze(pcm, sr, 2, 0.55), O.lossy_analyze(pcm, sr, 2, 0.55), sr)
+    o = O.lossy_analyze(pcm, sr, 2, 0.55)
+    compare_lossy_stage(ctx.lossy_analyze(pcm, sr, 2, 0.55), o, sr)
+    ctx.force_path(4)          # the lock-step stereo form has its own band-statistics code: other band tables too
+    compare_lossy_stage(ctx.lossy_analyze(pcm, sr, 2, 0.55), o, sr, tag="path4")
+    ctx.force_path(0)
 
 
 def test_chain_and_frame_parallel_forms_give_identical_files(ctx):
@@ -151,9 +211,12 @@ def test_chain_and_frame_parallel_forms_give_identical_files(ctx):
     b = ctx.encode_lossy(pcm, 44100, 2, 0.55)
     ctx.force_path(3)
     c = ctx.encode_lossy(pcm, 44100, 2, 0.55)
+    ctx.force_path(4)
+    d = ctx.encode_lossy(pcm, 44100, 2, 0.55)
     ctx.force_path(0)
     assert a == b
     assert a == c
+    assert a == d
 
 
 @pytest.mark.parametrize("q", [0.0, 0.55, 1.0])
@@ -166,8 +229,11 @@ def test_three_wave_pipeline_matches_chain_on_a_ragged_batch(ctx, q):
     a = ctx.encode_batch(1, clips, 44100, 2, q)
     ctx.force_path(3)
     b = ctx.encode_batch(1, clips, 44100, 2, q)
+    ctx.force_path(4)     # lock-step stereo transform wave, persistent workgroups dealing the clips dynamically
+    c = ctx.encode_batch(1, clips, 44100, 2, q)
     ctx.force_path(0)
     assert a == b
+    assert a == c
 
 
 @pytest.mark.parametrize("ch", [1, 2])
