@@ -122,14 +122,20 @@ def main():
 
     gather = None
     if world > 1:
-        from flo_amd.dist import BitstreamGather
-        gather = BitstreamGather(ctx, batch, dist, rank, world, local_rank)
+        # the exchange step lives behind the C ABI (flo_dist_*: RCCL directly, own stream, double-buffered); torch's
+        # process group only carries the 128-byte rendezvous token from rank 0 to the others
+        from flo_amd.dist import ID_BYTES, NativeGather, unique_id
+        tok = torch.zeros(ID_BYTES, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        if rank == 0:
+            tok.copy_(torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8))
+        dist.broadcast(tok, src=0)
+        gather = NativeGather(ctx, bytes(tok.cpu().numpy().tobytes()), rank, world, 0)
 
     def step():
         batch.encode(args.path)
         batch.sync()
         if gather is not None:
-            gather.run()
+            gather.submit(batch)
 
     def barrier():
         torch.cuda.synchronize()

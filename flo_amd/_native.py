@@ -24,6 +24,8 @@ EXPORTS = [
     "flo_batch_device_files", "flo_batch_pack_files",
     "flo_ctx_profile_enable", "flo_ctx_profile_query", "flo_ctx_profile_reset", "flo_ctx_force_path", "flo_ctx_stream",
     "flo_mdct_forward", "flo_lossy_analyze", "flo_lossy_quantize", "flo_sparse_pack",
+    "flo_dist_unique_id", "flo_dist_create", "flo_dist_destroy", "flo_dist_gather_submit", "flo_dist_gather_flush",
+    "flo_dist_gather_result", "flo_dist_stream",
 ]
 
 
@@ -97,6 +99,15 @@ def lib():
     L.flo_lossy_analyze.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_float, vp, vp, vp, C.POINTER(sz)]
     L.flo_lossy_quantize.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_float, C.c_int, vp, vp]
     L.flo_sparse_pack.argtypes = [vp, vp, sz, C.c_int, vp, sz, vp]
+    L.flo_dist_unique_id.argtypes = [vp]
+    L.flo_dist_create.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.flo_dist_destroy.argtypes = [vp]
+    L.flo_dist_destroy.restype = None
+    L.flo_dist_gather_submit.argtypes = [vp, vp]
+    L.flo_dist_gather_flush.argtypes = [vp]
+    L.flo_dist_gather_result.argtypes = [vp, C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint64))]
+    L.flo_dist_stream.argtypes = [vp]
+    L.flo_dist_stream.restype = vp
     L.flo_decode.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
     L.flo_decode_lossless_i32.argtypes = L.flo_decode.argtypes
     L.flo_probe_container.argtypes = [C.c_char_p, sz, C.POINTER(ContainerInfo), C.c_char_p, sz]

@@ -1,6 +1,7 @@
 // flo_api.cpp — C ABI of libflo_hip.so (see include/flo_hip.h): context, device-resident batches, .flo assembly.
 // Host code only; the kernels live in lossy_kernels.hip / lossless_kernels.hip.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -304,7 +305,8 @@ struct flo_batch {
     short *d_dbg_q = nullptr;
     unsigned short *d_dbg_sfw = nullptr;
     const float *d_in_coeffs = nullptr;
-    uint64_t *d_pack_plan = nullptr;
+    uint64_t *d_pack_plan = nullptr, *h_pack_plan = nullptr;
+    hipEvent_t ev_pack_plan = nullptr;
     unsigned long long *d_stamps = nullptr;
     int exact = 0;
     // results (host, valid after sync)
@@ -327,6 +329,8 @@ extern "C" void flo_batch_destroy(flo_batch *b) {
                     b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw, b->d_pack_plan, b->d_next};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    if (b->h_pack_plan) hipHostFree(b->h_pack_plan);
+    if (b->ev_pack_plan) hipEventDestroy(b->ev_pack_plan);
     if (b->ll) lossless_plan_destroy(b->ll);
     delete b;
 }
@@ -719,15 +723,21 @@ static int pack_impl(flo_batch *b, bool files, void *dst_device, size_t dst_cap,
     offsets[b->n_clips] = pos;
     if (pos > dst_cap) return fail(c, FLO_ERR_ARG, "packed stream buffer too small");
     if (!b->n_clips || !pos) return FLO_OK;
-    if (!b->d_pack_plan) HIPCHK(c, hipMalloc(&b->d_pack_plan, 3 * b->n_clips * 8));
-    std::vector<uint64_t> plan(3 * b->n_clips);
+    if (!b->d_pack_plan) {
+        HIPCHK(c, hipMalloc(&b->d_pack_plan, 3 * b->n_clips * 8));
+        HIPCHK(c, hipHostMalloc(&b->h_pack_plan, 3 * b->n_clips * 8));   // pinned: the copy below is truly asynchronous
+        HIPCHK(c, hipEventCreateWithFlags(&b->ev_pack_plan, hipEventDisableTiming));
+    } else {
+        HIPCHK(c, hipEventSynchronize(b->ev_pack_plan));   // the previous pack's copy has read the plan (long ago)
+    }
+    uint64_t *plan = b->h_pack_plan;
     for (size_t i = 0; i < b->n_clips; i++) {
         plan[i] = offs[i];
         plan[b->n_clips + i] = offsets[i];
         plan[2 * b->n_clips + i] = sizes[i];
     }
-    HIPCHK(c, hipMemcpyAsync(b->d_pack_plan, plan.data(), plan.size() * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // plan is a stack-lifetime host buffer
+    HIPCHK(c, hipMemcpyAsync(b->d_pack_plan, plan, 3 * b->n_clips * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(b->ev_pack_plan, c->stream));
     const unsigned long long *dp = (const unsigned long long *)b->d_pack_plan;
     return timed_launch(c, "pack_streams", [&] {
         return launch_pack_streams(base, dp, dp + b->n_clips, dp + 2 * b->n_clips, (int)b->n_clips, (uint8_t *)dst_device, c->stream);
@@ -1203,3 +1213,220 @@ extern "C" int flo_decode_lossless_i32(flo_ctx *c, const uint8_t *flo, size_t le
                                        uint32_t *sample_rate, uint8_t *channels) {
     return decode_impl(c, flo, len, nullptr, pcm, n_interleaved, sample_rate, channels);
 }
+
+// ------------------------------------------------------------------------------------------------ multi-GPU
+// One process per GPU. Clips shard across ranks with no data-path collective during the encode; the one
+// exchange step per batch is a variable-size gather of every rank's finished .flo files to the root, written directly
+// against RCCL: ncclAllGather of one u64 per rank (the packed size), then grouped ncclSend / ncclRecv - on the fully
+// connected xGMI node every peer has its own link to the root, so the seven transfers run in parallel where a ring
+// collective would be bound by one link. Everything runs on a side stream of its own and is double-buffered: the
+// transfer of step k overlaps the encode of step k + 1. No host synchronisation sits on that path: the sizes of step k
+// travel to pinned host memory asynchronously and are only read when step k + 1 is submitted (by then they have long
+// arrived), which is when the transfers of step k are posted; flo_dist_gather_flush posts and awaits the last ones.
+struct flo_dist {
+    flo_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, root = 0;
+    hipStream_t cs = nullptr;                 // communication stream
+    // per slot (step parity)
+    uint8_t *send[2] = {nullptr, nullptr};
+    size_t send_cap[2] = {0, 0};
+    uint64_t send_bytes[2] = {0, 0};
+    uint8_t *recv[2] = {nullptr, nullptr};    // root only
+    size_t recv_cap[2] = {0, 0};
+    uint64_t *d_sizes[2] = {nullptr, nullptr};   // [world] device
+    uint64_t *h_sizes[2] = {nullptr, nullptr};   // [world] pinned host
+    uint64_t *h_mine[2] = {nullptr, nullptr};    // pinned host: this rank's packed size
+    uint64_t *d_mine[2] = {nullptr, nullptr};
+    hipEvent_t ev_packed[2] = {nullptr, nullptr}, ev_sizes[2] = {nullptr, nullptr}, ev_moved[2] = {nullptr, nullptr};
+    bool posted[2] = {true, true};            // the slot's transfers have been posted (nothing pending)
+    bool used[2] = {false, false};
+    uint64_t submits = 0;
+    std::vector<uint64_t> pack_off;           // scratch: per-clip offsets of the last pack
+    // result of the most recently completed step (root)
+    std::vector<uint64_t> res_off, res_size;
+    int res_slot = -1;
+};
+
+#define NCCLCHK(ctx, expr)                                                                              \
+    do {                                                                                                \
+        ncclResult_t r_ = (expr);                                                                       \
+        if (r_ != ncclSuccess) return fail(ctx, FLO_ERR_DEVICE, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+
+extern "C" int flo_dist_unique_id(uint8_t *id) {
+    if (!id) return FLO_ERR_ARG;
+    static_assert(FLO_DIST_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId u;
+    ncclResult_t r = ncclGetUniqueId(&u);
+    if (r != ncclSuccess) {
+        g_create_err = std::string("ncclGetUniqueId: ") + ncclGetErrorString(r);
+        return FLO_ERR_DEVICE;
+    }
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return FLO_OK;
+}
+
+extern "C" void flo_dist_destroy(flo_dist *d) {
+    if (!d) return;
+    hipSetDevice(d->ctx->device);
+    if (d->cs) hipStreamSynchronize(d->cs);
+    for (int s = 0; s < 2; s++) {
+        if (d->send[s]) hipFree(d->send[s]);
+        if (d->recv[s]) hipFree(d->recv[s]);
+        if (d->d_sizes[s]) hipFree(d->d_sizes[s]);
+        if (d->d_mine[s]) hipFree(d->d_mine[s]);
+        if (d->h_sizes[s]) hipHostFree(d->h_sizes[s]);
+        if (d->h_mine[s]) hipHostFree(d->h_mine[s]);
+        if (d->ev_packed[s]) hipEventDestroy(d->ev_packed[s]);
+        if (d->ev_sizes[s]) hipEventDestroy(d->ev_sizes[s]);
+        if (d->ev_moved[s]) hipEventDestroy(d->ev_moved[s]);
+    }
+    if (d->comm) ncclCommDestroy(d->comm);
+    if (d->cs) hipStreamDestroy(d->cs);
+    delete d;
+}
+
+extern "C" int flo_dist_create(flo_ctx *c, const uint8_t *id, int rank, int world, int root, flo_dist **out) {
+    if (!c || !id || !out || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world) return FLO_ERR_ARG;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    flo_dist *d = new flo_dist();
+    d->ctx = c;
+    d->rank = rank;
+    d->world = world;
+    d->root = root;
+    auto bail = [&](int rc) {
+        flo_dist_destroy(d);
+        return rc;
+    };
+    if (hipStreamCreateWithFlags(&d->cs, hipStreamNonBlocking) != hipSuccess) return bail(fail(c, FLO_ERR_DEVICE, "hipStreamCreate (communication stream)"));
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    ncclResult_t r = ncclCommInitRank(&d->comm, world, u, rank);
+    if (r != ncclSuccess) return bail(fail(c, FLO_ERR_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)));
+    for (int s = 0; s < 2; s++) {
+        if (hipMalloc(&d->d_sizes[s], (size_t)world * 8) != hipSuccess || hipMalloc(&d->d_mine[s], 8) != hipSuccess ||
+            hipHostMalloc(&d->h_sizes[s], (size_t)world * 8) != hipSuccess || hipHostMalloc(&d->h_mine[s], 8) != hipSuccess ||
+            hipEventCreateWithFlags(&d->ev_packed[s], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d->ev_sizes[s], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d->ev_moved[s], hipEventDisableTiming) != hipSuccess)
+            return bail(fail(c, FLO_ERR_NOMEM, "flo_dist_create: buffers"));
+    }
+    *out = d;
+    return FLO_OK;
+}
+
+// (re)allocate a device buffer to hold `need` bytes; growing waits for the work that may still use the old one
+static int dist_reserve(flo_dist *d, uint8_t **buf, size_t *cap, size_t need) {
+    if (*cap >= need) return FLO_OK;
+    flo_ctx *c = d->ctx;
+    HIPCHK(c, hipStreamSynchronize(d->cs));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (*buf) HIPCHK(c, hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    const size_t want = need + need / 4 + 4096;
+    hipError_t e = hipMalloc(buf, want);
+    if (e != hipSuccess) return fail(c, FLO_ERR_NOMEM, std::string("gather buffer: ") + hipGetErrorString(e));
+    *cap = want;
+    return FLO_OK;
+}
+
+// post the point-to-point transfers of slot s (its sizes have arrived on the host, or are awaited here)
+static int dist_post(flo_dist *d, int s) {
+    flo_ctx *c = d->ctx;
+    if (d->posted[s]) return FLO_OK;
+    HIPCHK(c, hipEventSynchronize(d->ev_sizes[s]));   // recorded a whole step ago: no stall in steady state
+    const uint64_t *sz = d->h_sizes[s];
+    if (d->rank == d->root) {
+        uint64_t total = 0;
+        d->res_off.assign(d->world, 0);
+        d->res_size.assign(sz, sz + d->world);
+        for (int r = 0; r < d->world; r++) {
+            d->res_off[r] = total;
+            total += (sz[r] + 255) & ~(uint64_t)255;
+        }
+        int rc = dist_reserve(d, &d->recv[s], &d->recv_cap[s], total ? total : 256);
+        if (rc != FLO_OK) return rc;
+        // the root's own files: device-to-device copy on the communication stream
+        if (sz[d->root]) HIPCHK(c, hipMemcpyAsync(d->recv[s] + d->res_off[d->root], d->send[s], sz[d->root], hipMemcpyDeviceToDevice, d->cs));
+        NCCLCHK(c, ncclGroupStart());
+        for (int r = 0; r < d->world; r++)
+            if (r != d->root && sz[r]) NCCLCHK(c, ncclRecv(d->recv[s] + d->res_off[r], sz[r], ncclUint8, r, d->comm, d->cs));
+        NCCLCHK(c, ncclGroupEnd());
+        d->res_slot = s;
+    } else if (sz[d->rank]) {
+        NCCLCHK(c, ncclGroupStart());
+        NCCLCHK(c, ncclSend(d->send[s], sz[d->rank], ncclUint8, d->root, d->comm, d->cs));
+        NCCLCHK(c, ncclGroupEnd());
+    }
+    HIPCHK(c, hipEventRecord(d->ev_moved[s], d->cs));   // the slot's send buffer may be packed into again behind this
+    d->posted[s] = true;
+    return FLO_OK;
+}
+
+extern "C" int flo_dist_gather_submit(flo_dist *d, flo_batch *b) {
+    if (!d || !b) return FLO_ERR_ARG;
+    flo_ctx *c = d->ctx;
+    if (b->ctx != c) return fail(c, FLO_ERR_ARG, "batch and communicator belong to different contexts");
+    if (!b->synced) return fail(c, FLO_ERR_STATE, "call flo_batch_encode + flo_batch_sync first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int s = (int)(d->submits & 1), prev = s ^ 1;
+    // 1. this slot's previous transfers (two submits ago) were posted one submit ago; its send buffer is free once they
+    //    have run: the pack kernel waits for that on the device, the host does not
+    int rc = dist_post(d, s);   // (only pending when submits were skipped; normally a no-op)
+    if (rc != FLO_OK) return rc;
+    // 2. pack this batch's finished files into the slot's send buffer (ctx stream)
+    const uint8_t *base;
+    const uint64_t *offs, *sizes;
+    rc = flo_batch_device_files(b, &base, &offs, &sizes);
+    if (rc != FLO_OK) return rc;
+    uint64_t need = 0;
+    for (size_t i = 0; i < b->n_clips; i++) need += (sizes[i] + 15) & ~(uint64_t)15;
+    rc = dist_reserve(d, &d->send[s], &d->send_cap[s], need ? need : 16);
+    if (rc != FLO_OK) return rc;
+    if (d->used[s]) HIPCHK(c, hipStreamWaitEvent(c->stream, d->ev_moved[s], 0));
+    d->pack_off.resize(b->n_clips + 1);
+    rc = flo_batch_pack_files(b, d->send[s], d->send_cap[s], d->pack_off.data());
+    if (rc != FLO_OK) return rc;
+    d->send_bytes[s] = d->pack_off[b->n_clips];
+    HIPCHK(c, hipEventRecord(d->ev_packed[s], c->stream));
+    // 3. sizes: all-gather on the communication stream, then to pinned host memory (asynchronous)
+    *d->h_mine[s] = d->send_bytes[s];
+    HIPCHK(c, hipMemcpyAsync(d->d_mine[s], d->h_mine[s], 8, hipMemcpyHostToDevice, d->cs));
+    NCCLCHK(c, ncclAllGather(d->d_mine[s], d->d_sizes[s], 1, ncclUint64, d->comm, d->cs));
+    HIPCHK(c, hipMemcpyAsync(d->h_sizes[s], d->d_sizes[s], (size_t)d->world * 8, hipMemcpyDeviceToHost, d->cs));
+    HIPCHK(c, hipEventRecord(d->ev_sizes[s], d->cs));
+    HIPCHK(c, hipStreamWaitEvent(d->cs, d->ev_packed[s], 0));   // the payload transfers (posted next submit) read the packed buffer
+    d->posted[s] = false;
+    d->used[s] = true;
+    d->submits++;
+    // 4. the transfers of the previous submit: their sizes arrived during the step that has just been encoded
+    return dist_post(d, prev);
+}
+
+extern "C" int flo_dist_gather_flush(flo_dist *d) {
+    if (!d) return FLO_ERR_ARG;
+    flo_ctx *c = d->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int last = (int)((d->submits + 1) & 1);   // slot of the most recent submit
+    int rc = dist_post(d, last ^ 1);
+    if (rc == FLO_OK) rc = dist_post(d, last);
+    if (rc != FLO_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(d->cs));
+    return FLO_OK;
+}
+
+extern "C" int flo_dist_gather_result(flo_dist *d, const uint8_t **base, const uint64_t **rank_offsets,
+                                      const uint64_t **rank_sizes) {
+    if (!d) return FLO_ERR_ARG;
+    if (d->rank != d->root) return fail(d->ctx, FLO_ERR_STATE, "only the root holds the gathered files");
+    if (d->res_slot < 0) return fail(d->ctx, FLO_ERR_STATE, "nothing has been gathered yet");
+    if (base) *base = d->recv[d->res_slot];
+    if (rank_offsets) *rank_offsets = d->res_off.data();
+    if (rank_sizes) *rank_sizes = d->res_size.data();
+    return FLO_OK;
+}
+
+extern "C" void *flo_dist_stream(flo_dist *d) { return d ? (void *)d->cs : nullptr; }

@@ -1,13 +1,20 @@
 """Data-parallel sharding of a clip corpus across the GPUs of one node, and the one exchange step of the path:
 a variable-size gather of the packed bitstreams to rank 0 (RCCL over xGMI when the process group is "nccl").
 
+The exchange step of the product is `NativeGather` below: a thin caller of flo_dist_* in the C ABI (RCCL directly, own
+stream, double-buffered). `gather_payloads` / `PipelinedGather` / `BitstreamGather` are the same protocol over a
+torch.distributed process group; they are what the world-size-2 `gloo` tests on CPU exercise (RCCL needs GPUs).
+
 Clips are independent, so ranks never talk during the encode; the only communication is
   1. all_gather of one int64 per rank (payload bytes), and
   2. rank r > 0 sends its packed payload straight to rank 0 (point-to-point: on the fully connected xGMI node each
      peer has its own link to the root, so the seven transfers run in parallel; a ring collective would be slower).
 The payload is the compressed stream (about a tenth of the PCM bytes), so this step is small next to the encode.
 """
+import ctypes as C
 from typing import List, Sequence, Tuple
+
+ID_BYTES = 128
 
 
 def shard_clips(n_samples: Sequence[int], world: int) -> List[List[int]]:
@@ -157,3 +164,53 @@ class BitstreamGather:
     @property
     def last_total(self):
         return sum(self.pipe.last_sizes) if self.pipe.last_sizes else 0
+
+
+def unique_id() -> bytes:
+    """flo_dist_unique_id: the RCCL rendezvous token rank 0 makes and shares with the other ranks by any side channel."""
+    from . import _native
+    L = _native.lib()
+    buf = C.create_string_buffer(ID_BYTES)
+    if L.flo_dist_unique_id(buf) != 0:
+        raise _native.FloError(L.flo_last_create_error().decode())
+    return buf.raw
+
+
+class NativeGather:
+    """The multi-GPU exchange step behind the C ABI (flo_dist_* in include/flo_hip.h): RCCL directly, on the library's
+    own communication stream, double-buffered, no host synchronisation per step. This object only forwards.
+
+        g = NativeGather(ctx, id_bytes, rank, world)      # all ranks; id_bytes = unique_id() made on rank 0
+        per step:  batch.encode(); batch.sync(); g.submit(batch)
+        at the end: g.flush();  root: g.result() -> (device pointer, offsets by rank, sizes by rank)
+    """
+
+    def __init__(self, ctx, id_bytes: bytes, rank: int, world: int, root: int = 0):
+        assert len(id_bytes) == ID_BYTES
+        self.ctx, self._L, self.rank, self.world, self.root = ctx, ctx._L, rank, world, root
+        h = C.c_void_p()
+        ctx._chk(self._L.flo_dist_create(ctx._h, id_bytes, rank, world, root, C.byref(h)))
+        self._h = h
+
+    def submit(self, batch):
+        self.ctx._chk(self._L.flo_dist_gather_submit(self._h, batch._h))
+
+    def flush(self):
+        self.ctx._chk(self._L.flo_dist_gather_flush(self._h))
+
+    def result(self):
+        base = C.c_void_p()
+        offs, sizes = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        self.ctx._chk(self._L.flo_dist_gather_result(self._h, C.byref(base), C.byref(offs), C.byref(sizes)))
+        return base.value, [offs[i] for i in range(self.world)], [sizes[i] for i in range(self.world)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.flo_dist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -140,6 +140,31 @@ int flo_batch_pack_files(flo_batch *b, void *dst_device, size_t dst_cap, uint64_
  * offsets[i] floats (host array, n_clips entries). The payload never leaves HBM: full-size round-trip checks. */
 int flo_batch_decode(flo_batch *b, float *dst_device, size_t dst_cap_floats, uint64_t *offsets);
 
+/* ---- multi-GPU: one process per GPU, one exchange step per batch -------------------------
+ * Clips shard across ranks with no communication during the encode. The exchange step is the variable-size gather of
+ * every rank's finished .flo files to the root, written directly against RCCL over xGMI: ncclAllGather of the packed
+ * sizes, then grouped ncclSend / ncclRecv on a communication stream of the library's own, double-buffered so that the
+ * transfer of step k overlaps the encode of step k + 1. (The reference has no counterpart: its callers encode clips one
+ * after the other in one thread, reflo/src/lib.rs:286-306.)
+ *   rank 0:   flo_dist_unique_id(id); share id with the other ranks by any side channel (file, socket, MPI, ...)
+ *   all:      flo_dist_create(ctx, id, rank, world, root, &d);
+ *   per step: flo_batch_encode(b, 0); flo_batch_sync(b); flo_dist_gather_submit(d, b);
+ *   at the end: flo_dist_gather_flush(d);   root: flo_dist_gather_result(d, &base, &offs, &sizes)
+ * gather_submit never waits on the host for the device: it packs the batch's files (device), all-gathers the packed
+ * sizes into pinned host memory (asynchronous) and posts the point-to-point transfers of the PREVIOUS submit, whose
+ * sizes arrived while this step was being encoded. */
+typedef struct flo_dist flo_dist;
+#define FLO_DIST_ID_BYTES 128
+int flo_dist_unique_id(uint8_t *id /* FLO_DIST_ID_BYTES */);
+int flo_dist_create(flo_ctx *ctx, const uint8_t *id, int rank, int world, int root, flo_dist **out);
+void flo_dist_destroy(flo_dist *d);
+int flo_dist_gather_submit(flo_dist *d, flo_batch *b);
+int flo_dist_gather_flush(flo_dist *d);
+/* root, after a flush: rank r's packed files (each a complete .flo file without META, starts 16-byte aligned, lengths
+ * in their headers) lie at base + rank_offsets[r], rank_sizes[r] bytes, in device memory owned by d */
+int flo_dist_gather_result(flo_dist *d, const uint8_t **base, const uint64_t **rank_offsets, const uint64_t **rank_sizes);
+void *flo_dist_stream(flo_dist *d);   /* hipStream_t of the communication stream */
+
 /* ---- measurement hooks ----------------------------------------------------------------------------- */
 /* When enabled, every launch of a named kernel on the ctx stream is bracketed by hipEvents on that stream. */
 int flo_ctx_profile_enable(flo_ctx *ctx, int on);

@@ -34,6 +34,7 @@ def test_product_does_not_reference_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", os.path.join(ROOT, "flo_amd", "libflo_hip.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out and "amdhip64" in out
+    assert "librccl" in out        # the multi-GPU exchange step (flo_dist_*) is written against RCCL directly
 
 
 def test_fails_loudly_without_gpu():

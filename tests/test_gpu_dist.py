@@ -1,0 +1,124 @@
+"""The multi-GPU exchange step behind the C ABI (flo_dist_*: RCCL directly). A gpurun box has one GPU: the single-rank
+case runs the whole code path (all-gather of sizes, root copy, double buffering, deferred posting); the two-rank case
+puts two processes on the same GPU, which RCCL may refuse - then it is skipped and N > 1 stays covered by the gloo
+logic tests of test_dist_cpu.py plus the driver's multi-GPU run."""
+import ctypes
+import multiprocessing as mp
+import os
+
+import numpy as np
+import pytest
+
+import flofile
+import signals
+from gpu_util import ctx  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _d2h(ptr, n):
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    buf = (ctypes.c_uint8 * max(n, 1))()
+    assert hip.hipMemcpy(buf, ptr, n, 2) == 0
+    return bytes(buf[:n])
+
+
+def _split_files(blob):
+    """finished .flo files packed back to back at 16-byte aligned offsets: lengths come from their headers"""
+    out, pos = [], 0
+    while pos + 70 <= len(blob):
+        assert blob[pos:pos + 4] == b"FLO!", pos
+        toc, data = int.from_bytes(blob[pos + 38:pos + 46], "little"), int.from_bytes(blob[pos + 46:pos + 54], "little")
+        n = 70 + toc + data
+        out.append(blob[pos:pos + n])
+        pos += (n + 15) & ~15
+    return out
+
+
+def test_single_rank_gather_returns_the_batch_files(ctx):
+    import flo_amd
+    from flo_amd.dist import NativeGather, unique_id
+    lens = [0, 1000, 44100, 70001, 3 * 1024, 22050]
+    clips = [signals.music_like(44100, n, 2, seed=60 + i) for i, n in enumerate(lens)]
+    g = NativeGather(ctx, unique_id(), 0, 1, 0)
+    for mode, qol in ((flo_amd.MODE_LOSSY, 0.55), (flo_amd.MODE_LOSSLESS, 5)):
+        b = flo_amd.Batch(ctx, mode, [c.size for c in clips], 44100, 2, qol)
+        for i, c in enumerate(clips):
+            b.upload(i, c)
+        for step in range(4):          # several steps: both buffer slots, deferred posting, buffer reuse
+            b.encode(0)
+            b.sync()
+            g.submit(b)
+        g.flush()
+        base, offs, sizes = g.result()
+        assert offs == [0] and sizes[0] > 0
+        files = _split_files(_d2h(base, sizes[0]))
+        assert len(files) == len(clips)
+        for i in range(len(clips)):
+            assert files[i] == b.fetch(i), (mode, i)
+            assert flofile.parse(files[i]).crc_valid
+        b.close()
+    g.close()
+
+
+def _rank_main(rank, world, idq, outq):
+    try:
+        import flo_amd
+        from flo_amd.dist import NativeGather, unique_id
+        c = flo_amd.Context(0)
+        if rank == 0:
+            tok = unique_id()
+            for _ in range(world - 1):
+                idq.put(tok)
+        else:
+            tok = idq.get(timeout=120)
+        g = NativeGather(c, tok, rank, world, 0)
+        lens = [5000 + 777 * rank, 30000, 1024 * (rank + 1)]
+        clips = [signals.music_like(44100, n, 2, seed=100 * rank + i) for i, n in enumerate(lens)]
+        b = flo_amd.Batch(c, flo_amd.MODE_LOSSY, [x.size for x in clips], 44100, 2, 0.55)
+        for i, x in enumerate(clips):
+            b.upload(i, x)
+        for _ in range(3):
+            b.encode(0)
+            b.sync()
+            g.submit(b)
+        g.flush()
+        mine = [b.fetch(i) for i in range(len(clips))]
+        if rank == 0:
+            base, offs, sizes = g.result()
+            got = [_split_files(_d2h(base + offs[r], sizes[r])) for r in range(world)]
+            outq.put(("root", got, mine))
+        else:
+            outq.put(("peer", rank, mine))
+        g.close()
+        c.close()
+    except Exception as e:   # noqa: BLE001
+        outq.put(("error", rank, repr(e)))
+
+
+def test_two_ranks_on_one_gpu_if_rccl_allows_it():
+    mpc = mp.get_context("spawn")
+    idq, outq = mpc.Queue(), mpc.Queue()
+    world = 2
+    procs = [mpc.Process(target=_rank_main, args=(r, world, idq, outq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in range(world):
+            res.append(outq.get(timeout=240))
+    except Exception:   # noqa: BLE001
+        for p in procs:
+            p.kill()
+        pytest.skip("two RCCL ranks on one GPU did not come up on this box (N > 1 is the driver's multi-GPU run)")
+    for p in procs:
+        p.join(timeout=60)
+    errs = [r for r in res if r[0] == "error"]
+    if errs:
+        pytest.skip(f"RCCL refused two ranks on one GPU: {errs[0][2][:200]}")
+    root = [r for r in res if r[0] == "root"][0]
+    peer = [r for r in res if r[0] == "peer"][0]
+    got = root[1]
+    assert got[0] == root[2]          # the root's own files
+    assert got[1] == peer[2]          # the peer's files arrived byte for byte
