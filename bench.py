@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--no-single-clip", action="store_true")
     ap.add_argument("--no-lossless", action="store_true")
     ap.add_argument("--no-shard", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--cpu-clips", type=int, default=200)
     args = ap.parse_args()
 
@@ -258,6 +259,31 @@ def main():
                                    "value": round(n180 / d1 / 1e6, 1), "unit": "Msamples/s", "ms": round(d1 * 1e3, 4),
                                    "realtime_factor": round(n180 / d1 / (sr * ch), 1)}
         b1.close()
+
+    if not args.no_e2e and world == 1:
+        # the drop-in calls on HOST buffers (what encode_to_flo / Encoder::encode bind to): pageable PCM in, malloc'ed
+        # .flo files out, PCIe both ways included. Never `value`: the resident-batch rate above is the kernel's.
+        import numpy as np
+        from oracle import oracle as O      # only the synthetic-signal generator (shared integer-exact definition)
+        clips = [O.synth_clip(n_sf, ch, 0xF10A0D10, i) for i in range(64)]
+        for _ in range(3):
+            ctx.encode_lossy(clips[0], sr, ch, args.quality)
+        t6 = time.perf_counter()
+        for i in range(20):
+            ctx.encode_lossy(clips[i], sr, ch, args.quality)
+        d6 = (time.perf_counter() - t6) / 20
+        ctx.encode_batch(flo_amd.MODE_LOSSY, clips, sr, ch, args.quality)
+        best = None
+        for _ in range(3):
+            t7 = time.perf_counter()
+            ctx.encode_batch(flo_amd.MODE_LOSSY, clips, sr, ch, args.quality)
+            d7 = time.perf_counter() - t7
+            best = d7 if best is None else min(best, d7)
+        out["e2e"] = {"note": "host buffers in, .flo files out (H2D + encode + D2H through the C ABI); not the headline",
+                      "flo_encode_lossy_10s_clip_ms": round(d6 * 1e3, 4),
+                      "flo_encode_lossy_10s_clip_Msamples_s": round(n_il / d6 / 1e6, 1),
+                      "flo_encode_batch_64x10s_ms": round(best * 1e3, 3),
+                      "flo_encode_batch_64x10s_Msamples_s": round(64 * n_il / best / 1e6, 1)}
 
     if not args.no_lossless and world == 1:
         # BASELINE configs[4] shape (96 kHz stereo, level 5) as a batch; bit-exactness is the tests' business, this is

@@ -6,7 +6,7 @@ for v in "$@"; do
   if [ "$v" != "full" ]; then export FLO_HIP_LIB=$R/diag/libflo_$v.so; else unset FLO_HIP_LIB; fi
   out=$R/gpurun_out/pmc_$v; mkdir -p $out
   rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE \
-    -d $out -o run --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-single-clip --no-lossless --no-shard --clips-per-gpu ${CLIPS:-1250} --path ${BPATH:-0} > $out/log.txt 2>&1
+    -d $out -o run --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-single-clip --no-lossless --no-shard --no-e2e --clips-per-gpu ${CLIPS:-1250} --path ${BPATH:-0} > $out/log.txt 2>&1
   python - $out $v <<'PY'
 import csv,glob,os,collections,sys
 out=sys.argv[1]

@@ -6,7 +6,7 @@ out=$R/gpurun_out/pmc_lds
 mkdir -p $out
 cd $R
 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE \
-  -d $out -o run --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-single-clip --no-lossless --no-shard --clips-per-gpu ${1:-1250} > $out/log.txt 2>&1
+  -d $out -o run --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-single-clip --no-lossless --no-shard --no-e2e --clips-per-gpu ${1:-1250} > $out/log.txt 2>&1
 python - <<'PY'
 import csv,glob,os,collections
 out=os.path.join(os.environ['GRAFT_REPO_ROOT'],'gpurun_out','pmc_lds')

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +16,8 @@
 #include "container.hpp"
 #include "container_kernels.hpp"
 #include "decode_kernels.hpp"
+#include "devpool.hpp"
+#include "stager.hpp"
 #include "lossless_kernels.hpp"
 #include "lossy_kernels.hpp"
 #include "tables.hpp"
@@ -48,6 +51,8 @@ struct flo_ctx {
     std::map<std::string, ProfSum> prof_sum;
     int force_path = 0;
     hipDeviceProp_t prop{};
+    Stager *stager = nullptr;   // pinned staging ring + copy threads of the host-buffer entry points (made on first use)
+    hipStream_t up_stream = nullptr, down_stream = nullptr;   // uploads / downloads of flo_encode_batch's pipeline
 };
 
 static thread_local std::string g_create_err;
@@ -102,6 +107,10 @@ extern "C" int flo_ctx_create(int device, flo_ctx **out) {
         restore();
         return FLO_ERR_DEVICE;
     }
+    {
+        std::string serr;
+        c->stager = stager_create(serr);   // light: pinned buffers and copy threads appear when first needed
+    }
     restore();
     *out = c;
     return FLO_OK;
@@ -120,6 +129,9 @@ extern "C" void flo_ctx_destroy(flo_ctx *c) {
         hipEventDestroy(r.b);
     }
     hipStreamDestroy(c->stream);
+    if (c->stager) stager_destroy(c->stager);
+    if (c->up_stream) hipStreamDestroy(c->up_stream);
+    if (c->down_stream) hipStreamDestroy(c->down_stream);
     delete c;
 }
 
@@ -305,7 +317,8 @@ struct flo_batch {
     short *d_dbg_q = nullptr;
     unsigned short *d_dbg_sfw = nullptr;
     const float *d_in_coeffs = nullptr;
-    uint64_t *d_pack_plan = nullptr, *h_pack_plan = nullptr;
+    uint64_t *d_pack_plan = nullptr;
+    uint64_t *pin_plan = nullptr;        // pinned: clip plan (4 n) | hops (n u32) | pack plan (3 n): read by asynchronous copies
     hipEvent_t ev_pack_plan = nullptr;
     unsigned long long *d_stamps = nullptr;
     int exact = 0;
@@ -328,9 +341,9 @@ extern "C" void flo_batch_destroy(flo_batch *b) {
     void *ptrs[] = {b->d_pcm, b->d_plan, b->d_hops, b->d_out, b->d_frame_size, b->d_clip_bytes, b->d_crc, b->d_part, b->d_at,
                     b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw, b->d_pack_plan, b->d_next};
     for (void *p : ptrs)
-        if (p) hipFree(p);
-    if (b->h_pack_plan) hipHostFree(b->h_pack_plan);
+        if (p) pool_free(p);
     if (b->ev_pack_plan) hipEventDestroy(b->ev_pack_plan);
+    if (b->pin_plan) stager_pinned_put(b->ctx->stager, b->pin_plan);
     if (b->ll) lossless_plan_destroy(b->ll);
     delete b;
 }
@@ -385,8 +398,18 @@ extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size
             return bail(e_ == hipErrorOutOfMemory ? FLO_ERR_NOMEM : FLO_ERR_DEVICE);                \
         }                                                                                           \
     } while (0)
-    BCHK(hipMalloc(&b->d_pcm, (b->total_floats + 4) * sizeof(float)));
-    if (mode == FLO_MODE_LOSSY) BCHK(hipMemset(b->d_pcm, 0, (b->total_floats + 4) * sizeof(float)));   // the padding
+    BCHK(pool_alloc(&b->d_pcm, (b->total_floats + 4) * sizeof(float)));
+    if (mode == FLO_MODE_LOSSY) {   // the zero padding behind every clip (the clips themselves are written by the caller)
+        if (n_clips <= 8) {
+            for (size_t i = 0; i < n_clips; i++) {
+                const uint64_t used = b->clip_nsf[i] * ch;
+                const uint64_t end = (i + 1 < n_clips ? b->clip_off[i + 1] : b->total_floats) + (i + 1 < n_clips ? 0 : 4);
+                BCHK(hipMemsetAsync(b->d_pcm + b->clip_off[i] + used, 0, (end - b->clip_off[i] - used) * sizeof(float), c->stream));
+            }
+        } else {
+            BCHK(hipMemsetAsync(b->d_pcm, 0, (b->total_floats + 4) * sizeof(float), c->stream));
+        }
+    }
     if (mode == FLO_MODE_LOSSY) {
         rc = get_tables(c, sr, qol, &b->ts);
         if (rc != FLO_OK) return bail(rc);
@@ -419,17 +442,27 @@ extern "C" int flo_batch_create(flo_ctx *c, int mode, size_t n_clips, const size
             plan[2 * n_clips + i] = b->clip_frame0[i];
             plan[3 * n_clips + i] = b->out_off[i];
         }
-        BCHK(hipMalloc(&b->d_plan, (plan.size() + 1) * 8));
-        BCHK(hipMalloc(&b->d_hops, (n_clips + 1) * 4));
-        BCHK(hipMalloc(&b->d_out, b->out_bytes + 64));
-        BCHK(hipMalloc(&b->d_frame_size, (b->total_frames + 1) * 4));
-        BCHK(hipMalloc(&b->d_clip_bytes, (n_clips + 1) * 8));
-        BCHK(hipMalloc(&b->d_crc, (n_clips + 1) * 4));
-        BCHK(hipMalloc(&b->d_next, 16));
-        BCHK(hipMalloc(&b->d_part, (n_clips * finish_parts_for(n_clips) + 1) * 4));
+        BCHK(pool_alloc(&b->d_plan, (plan.size() + 1) * 8));
+        BCHK(pool_alloc(&b->d_hops, (n_clips + 1) * 4));
+        BCHK(pool_alloc(&b->d_out, b->out_bytes + 64));
+        BCHK(pool_alloc(&b->d_frame_size, (b->total_frames + 1) * 4));
+        BCHK(pool_alloc(&b->d_clip_bytes, (n_clips + 1) * 8));
+        BCHK(pool_alloc(&b->d_crc, (n_clips + 1) * 4));
+        BCHK(pool_alloc(&b->d_next, 16));
+        BCHK(pool_alloc(&b->d_part, (n_clips * finish_parts_for(n_clips) + 1) * 4));
         if (n_clips) {
-            BCHK(hipMemcpy(b->d_plan, plan.data(), plan.size() * 8, hipMemcpyHostToDevice));
-            BCHK(hipMemcpy(b->d_hops, b->hops.data(), n_clips * 4, hipMemcpyHostToDevice));
+            // from pinned memory on the context's stream, in front of everything that will use them: a synchronous (or
+            // pageable "asynchronous") copy would wait for whatever this context's other batches have in flight
+            std::string perr;
+            b->pin_plan = (uint64_t *)stager_pinned_get(c->stager, (8 * n_clips + 8) * 8, perr);
+            if (!b->pin_plan) {
+                fail(c, FLO_ERR_NOMEM, perr);
+                return bail(FLO_ERR_NOMEM);
+            }
+            memcpy(b->pin_plan, plan.data(), plan.size() * 8);
+            memcpy(b->pin_plan + 4 * n_clips, b->hops.data(), n_clips * 4);
+            BCHK(hipMemcpyAsync(b->d_plan, b->pin_plan, plan.size() * 8, hipMemcpyHostToDevice, c->stream));
+            BCHK(hipMemcpyAsync(b->d_hops, b->pin_plan + 4 * n_clips, n_clips * 4, hipMemcpyHostToDevice, c->stream));
         }
         if (auto_form(b) == 2 && (rc = alloc_frame_scratch(b)) != FLO_OK) return bail(rc);
     } else {
@@ -498,10 +531,10 @@ static int alloc_frame_scratch(flo_batch *b) {
     flo_ctx *c = b->ctx;
     if (b->d_at || !b->total_frames) return FLO_OK;
     const size_t n = (size_t)b->total_frames * b->ch * 32 * sizeof(float);
-    HIPCHK(c, hipMalloc(&b->d_at, n));
-    HIPCHK(c, hipMalloc(&b->d_sprev, n));
-    HIPCHK(c, hipMalloc(&b->d_slots, (size_t)b->total_frames * lossy_slot_bytes(b->ch)));
-    HIPCHK(c, hipMalloc(&b->d_frame_off, (size_t)(b->total_frames + 1) * 8));
+    HIPCHK(c, pool_alloc(&b->d_at, n));
+    HIPCHK(c, pool_alloc(&b->d_sprev, n));
+    HIPCHK(c, pool_alloc(&b->d_slots, (size_t)b->total_frames * lossy_slot_bytes(b->ch)));
+    HIPCHK(c, pool_alloc(&b->d_frame_off, (size_t)(b->total_frames + 1) * 8));
     return FLO_OK;
 }
 
@@ -582,7 +615,7 @@ static int batch_encode_launch(flo_batch *b, int which) {
         rc = timed_launch(c, "lossy_chain2x", [&] { return launch_lossy_chain2x(A, c->stream); });
     } else if (which == 1 || ((which == 3 || which == 4) && b->ch != 2)) {
 #ifdef FLO_STAMPS
-        if (!b->d_stamps) HIPCHK(c, hipMalloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
+        if (!b->d_stamps) HIPCHK(c, pool_alloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
 #endif
         LossyArgs A = make_args(b);
         rc = timed_launch(c, "lossy_chain", [&] { return launch_lossy_chain(A, c->stream); });
@@ -622,11 +655,18 @@ static int batch_encode_launch(flo_batch *b, int which) {
     return timed_launch(c, "finish_files", [&] { return launch_finish_files(F, c->stream); });
 }
 
+static int batch_sync_impl(flo_batch *b, hipEvent_t done);
 extern "C" int flo_batch_sync(flo_batch *b) {
     if (!b) return FLO_ERR_ARG;
+    return batch_sync_impl(b, nullptr);
+}
+// done = nullptr: wait for the context's stream; else wait for that event only (recorded behind the batch's encode):
+// the pipeline of flo_encode_batch must not wait for the NEXT chunk's work that is already queued on the stream
+static int batch_sync_impl(flo_batch *b, hipEvent_t done) {
     flo_ctx *c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (done) HIPCHK(c, hipEventSynchronize(done));
+    else HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!b->encoded && b->encode_failed) return fail(c, FLO_ERR_STATE, "the last flo_batch_encode on this batch failed");
     if (b->encoded && !b->synced) {
         if (b->mode == FLO_MODE_LOSSY) {
@@ -634,8 +674,14 @@ extern "C" int flo_batch_sync(flo_batch *b) {
             // fetched on demand by the few host paths that want them
             b->h_clip_bytes.assign(b->n_clips, 0);
             b->h_frame_size.clear();
-            if (b->n_clips && b->total_frames)
-                HIPCHK(c, hipMemcpy(b->h_clip_bytes.data(), b->d_clip_bytes, b->n_clips * 8, hipMemcpyDeviceToHost));
+            if (b->n_clips && b->total_frames) {
+                if (done && c->down_stream) {   // pipeline: other streams are busy, a synchronous copy would queue behind them
+                    HIPCHK(c, hipMemcpyAsync(b->h_clip_bytes.data(), b->d_clip_bytes, b->n_clips * 8, hipMemcpyDeviceToHost, c->down_stream));
+                    HIPCHK(c, hipStreamSynchronize(c->down_stream));
+                } else {
+                    HIPCHK(c, hipMemcpy(b->h_clip_bytes.data(), b->d_clip_bytes, b->n_clips * 8, hipMemcpyDeviceToHost));
+                }
+            }
             for (size_t i = 0; i < b->n_clips; i++)
                 if (b->h_clip_bytes[i] > b->out_cap[i]) return fail(c, FLO_ERR_DEVICE, "bitstream overran its buffer");
 #ifdef FLO_STAMPS
@@ -724,13 +770,15 @@ static int pack_impl(flo_batch *b, bool files, void *dst_device, size_t dst_cap,
     if (pos > dst_cap) return fail(c, FLO_ERR_ARG, "packed stream buffer too small");
     if (!b->n_clips || !pos) return FLO_OK;
     if (!b->d_pack_plan) {
-        HIPCHK(c, hipMalloc(&b->d_pack_plan, 3 * b->n_clips * 8));
-        HIPCHK(c, hipHostMalloc(&b->h_pack_plan, 3 * b->n_clips * 8));   // pinned: the copy below is truly asynchronous
+        HIPCHK(c, pool_alloc(&b->d_pack_plan, 3 * b->n_clips * 8));
         HIPCHK(c, hipEventCreateWithFlags(&b->ev_pack_plan, hipEventDisableTiming));
     } else {
         HIPCHK(c, hipEventSynchronize(b->ev_pack_plan));   // the previous pack's copy has read the plan (long ago)
     }
-    uint64_t *plan = b->h_pack_plan;
+    std::string perr;
+    if (!b->pin_plan && !(b->pin_plan = (uint64_t *)stager_pinned_get(c->stager, (8 * b->n_clips + 8) * 8, perr)))
+        return fail(c, FLO_ERR_NOMEM, perr);
+    uint64_t *plan = b->pin_plan + 5 * b->n_clips;   // behind the clip plan (4 n) and the hops (n u32)
     for (size_t i = 0; i < b->n_clips; i++) {
         plan[i] = offs[i];
         plan[b->n_clips + i] = offsets[i];
@@ -779,24 +827,157 @@ extern "C" int flo_batch_fetch(flo_batch *b, size_t clip, const uint8_t *meta, s
 }
 
 // ------------------------------------------------------------------------------------------------ one-shot API
+static int ctx_stager(flo_ctx *c) {
+    if (c->stager && c->up_stream) return FLO_OK;
+    if (c->stager) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
+        return FLO_OK;
+    }
+    std::string err;
+    c->stager = stager_create(err);
+    if (!c->stager) return fail(c, FLO_ERR_NOMEM, err);
+    HIPCHK(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
+    return FLO_OK;
+}
+
+// all clips of a batch from host buffers, through the pinned staging ring
+static int batch_upload_all(flo_batch *b, const float *const *pcm, hipStream_t stream = nullptr) {
+    flo_ctx *c = b->ctx;
+    int rc = ctx_stager(c);
+    if (rc != FLO_OK) return rc;
+    std::vector<UploadSeg> segs;
+    segs.reserve(b->n_clips);
+    for (size_t i = 0; i < b->n_clips; i++) {
+        // a trailing partial sample-frame is not part of the clip (encoder.rs:174): it must not land in the zero padding
+        const uint64_t n_copy = b->mode == FLO_MODE_LOSSY ? b->clip_nsf[i] * b->ch : b->n_il[i];
+        if (n_copy) segs.push_back({b->d_pcm + b->clip_off[i], pcm[i], n_copy * sizeof(float)});
+    }
+    std::string err;
+    if (stager_upload(c->stager, segs, stream ? stream : c->stream, err) != 0) return fail(c, FLO_ERR_DEVICE, err);
+    b->encoded = b->synced = b->encode_failed = false;
+    return FLO_OK;
+}
+
+// The throughput entry point on host buffers, as a three-stage pipeline over chunks of clips: while chunk k is being
+// encoded, the copy threads and the upload stream bring in chunk k + 1 and the download stream takes the finished files
+// of chunk k - 1 out (one packed pinned transfer per chunk). The bytes are those of n_clips separate calls.
 extern "C" int flo_encode_batch(flo_ctx *c, int mode, size_t n_clips, const float *const *pcm, const size_t *n_il,
                                 uint32_t sr, uint8_t ch, float qol, uint8_t **outs, size_t *out_lens) {
     if (!c || (n_clips && (!pcm || !n_il || !outs || !out_lens))) return FLO_ERR_ARG;
-    flo_batch *b = nullptr;
-    int rc = flo_batch_create(c, mode, n_clips, n_il, sr, ch, qol, &b);
+    for (size_t i = 0; i < n_clips; i++)
+        if (n_il[i] && !pcm[i]) return FLO_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ctx_stager(c);
     if (rc != FLO_OK) return rc;
-    for (size_t i = 0; i < n_clips && rc == FLO_OK; i++) rc = flo_batch_upload(b, i, pcm[i]);
-    if (rc == FLO_OK) rc = flo_batch_encode(b, 0);
-    if (rc == FLO_OK) rc = flo_batch_sync(b);
     for (size_t i = 0; i < n_clips; i++) outs[i] = nullptr;
-    for (size_t i = 0; i < n_clips && rc == FLO_OK; i++) rc = flo_batch_fetch(b, i, nullptr, 0, &outs[i], &out_lens[i]);
-    if (rc != FLO_OK)
-        for (size_t i = 0; i < n_clips; i++) {
-            free(outs[i]);
-            outs[i] = nullptr;
+    const bool trace = getenv("FLO_TRACE") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = tnow();
+    // chunks of about 48 MB of PCM (at least one clip each)
+    struct Chunk {
+        size_t first = 0, count = 0;
+        flo_batch *b = nullptr;
+        uint8_t *d_packed = nullptr;
+        uint8_t *host = nullptr;
+        std::vector<uint64_t> po;
+        hipEvent_t up = nullptr, enc = nullptr;
+        bool encoded = false, taken = false;
+    };
+    std::vector<Chunk> chunks;
+    {
+        const uint64_t target = (uint64_t)48 << 20;
+        size_t i = 0;
+        while (i < n_clips) {
+            Chunk k;
+            k.first = i;
+            uint64_t bytes = 0;
+            while (i < n_clips && (k.count == 0 || bytes + n_il[i] * 4 <= target)) {
+                bytes += (uint64_t)n_il[i] * 4;
+                i++;
+                k.count++;
+            }
+            chunks.push_back(k);
         }
-    flo_batch_destroy(b);
-    return rc;
+    }
+    auto cleanup = [&](int code) {
+        hipStreamSynchronize(c->up_stream);
+        hipStreamSynchronize(c->stream);
+        hipStreamSynchronize(c->down_stream);
+        for (Chunk &k : chunks) {
+            if (k.d_packed) pool_free(k.d_packed);
+            if (k.host) stager_pinned_put(c->stager, k.host);
+            if (k.up) hipEventDestroy(k.up);
+            if (k.enc) hipEventDestroy(k.enc);
+            if (k.b) flo_batch_destroy(k.b);
+        }
+        if (code != FLO_OK)
+            for (size_t i = 0; i < n_clips; i++) {
+                free(outs[i]);
+                outs[i] = nullptr;
+            }
+        return code;
+    };
+    // stage 3 for one chunk: sizes, pack, download (asynchronous on the download stream)
+    auto take = [&](Chunk &k) -> int {
+        int r = batch_sync_impl(k.b, mode == FLO_MODE_LOSSY ? k.enc : nullptr);
+        if (r != FLO_OK) return r;
+        const uint8_t *base;
+        const uint64_t *offs, *sizes;
+        if ((r = flo_batch_device_files(k.b, &base, &offs, &sizes)) != FLO_OK) return r;
+        uint64_t need = 16;
+        for (size_t i = 0; i < k.count; i++) need += (sizes[i] + 15) & ~(uint64_t)15;
+        if (pool_alloc(&k.d_packed, need) != hipSuccess) return fail(c, FLO_ERR_NOMEM, "packed output buffer");
+        k.po.resize(k.count + 1);
+        if ((r = flo_batch_pack_files(k.b, k.d_packed, need, k.po.data())) != FLO_OK) return r;
+        std::string err;
+        k.host = (uint8_t *)stager_pinned_get(c->stager, need, err);
+        if (!k.host) return fail(c, FLO_ERR_NOMEM, err);
+        HIPCHK(c, hipEventRecord(k.up, c->stream));   // (the upload event has served its purpose: reused for "packed")
+        HIPCHK(c, hipStreamWaitEvent(c->down_stream, k.up, 0));
+        HIPCHK(c, hipMemcpyAsync(k.host, k.d_packed, k.po[k.count], hipMemcpyDeviceToHost, c->down_stream));
+        for (size_t i = 0; i < k.count; i++) out_lens[k.first + i] = sizes[i];
+        k.taken = true;
+        return FLO_OK;
+    };
+    for (size_t ci = 0; ci < chunks.size(); ci++) {
+        Chunk &k = chunks[ci];
+        const double ta = tnow();
+        if ((rc = flo_batch_create(c, mode, k.count, n_il + k.first, sr, ch, qol, &k.b)) != FLO_OK) return cleanup(rc);
+        const double tb = tnow();
+        if (hipEventCreateWithFlags(&k.up, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&k.enc, hipEventDisableTiming) != hipSuccess)
+            return cleanup(fail(c, FLO_ERR_DEVICE, "hipEventCreate"));
+        // the batch's padding memset ran on the ctx stream: the uploads must land behind it
+        HIPCHK(c, hipEventRecord(k.enc, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->up_stream, k.enc, 0));
+        if ((rc = batch_upload_all(k.b, pcm + k.first, c->up_stream)) != FLO_OK) return cleanup(rc);
+        const double tc = tnow();
+        HIPCHK(c, hipEventRecord(k.up, c->up_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, k.up, 0));
+        if ((rc = flo_batch_encode(k.b, 0)) != FLO_OK) return cleanup(rc);
+        HIPCHK(c, hipEventRecord(k.enc, c->stream));   // this chunk's files are finished behind this point
+        k.encoded = true;
+        const double td = tnow();
+        if (ci > 0 && (rc = take(chunks[ci - 1])) != FLO_OK) return cleanup(rc);
+        if (trace) fprintf(stderr, "  chunk %zu: create %.3f upload %.3f encode-enqueue %.3f take(prev) %.3f ms\n", ci, (tb - ta) * 1e3, (tc - tb) * 1e3, (td - tc) * 1e3, (tnow() - td) * 1e3);
+    }
+    if (!chunks.empty() && (rc = take(chunks.back())) != FLO_OK) return cleanup(rc);
+    if (hipStreamSynchronize(c->down_stream) != hipSuccess) return cleanup(fail(c, FLO_ERR_DEVICE, "download of the finished files failed"));
+    const double t1 = tnow();
+    // cut the packed transfers into the per-clip buffers the caller owns (the copy threads share the work)
+    std::vector<UploadSeg> cuts;
+    cuts.reserve(n_clips);
+    for (Chunk &k : chunks)
+        for (size_t i = 0; i < k.count; i++) {
+            const size_t g = k.first + i;
+            outs[g] = (uint8_t *)malloc(out_lens[g] ? out_lens[g] : 1);
+            if (!outs[g]) return cleanup(fail(c, FLO_ERR_NOMEM, "malloc failed"));
+            cuts.push_back({outs[g], k.host + k.po[i], out_lens[g]});
+        }
+    stager_memcpy_many(c->stager, cuts);
+    if (trace) fprintf(stderr, "[flo_encode_batch] %zu chunks: pipeline %.3f ms, cut %.3f ms\n", chunks.size(), (t1 - t0) * 1e3, (tnow() - t1) * 1e3);
+    return cleanup(FLO_OK);
 }
 
 static int encode_one(flo_ctx *c, int mode, const float *pcm, size_t n, uint32_t sr, uint8_t ch, float qol,
@@ -806,7 +987,10 @@ static int encode_one(flo_ctx *c, int mode, const float *pcm, size_t n, uint32_t
     int rc = flo_batch_create(c, mode, 1, &n, sr, ch, qol, &b);
     if (rc != FLO_OK) return rc;
     b->bit_depth = bit_depth;
-    rc = flo_batch_upload(b, 0, pcm);
+    {
+        const float *one[1] = {pcm};
+        rc = batch_upload_all(b, one);
+    }
     if (rc == FLO_OK) rc = flo_batch_encode(b, 0);
     if (rc == FLO_OK) rc = flo_batch_sync(b);
     if (rc == FLO_OK) rc = flo_batch_fetch(b, 0, meta, meta_len, out, out_len);
@@ -864,8 +1048,8 @@ static int analyze_common(flo_ctx *c, const float *pcm, size_t n, const float *i
         return code;
     };
     const size_t per = hops * ch;
-    if (hipMalloc(&b->d_dbg_coeffs, per * 1024 * 4 + 16) != hipSuccess || hipMalloc(&b->d_dbg_q, per * 1024 * 2 + 16) != hipSuccess ||
-        hipMalloc(&b->d_dbg_sfw, per * 25 * 2 + 16) != hipSuccess)
+    if (pool_alloc(&b->d_dbg_coeffs, per * 1024 * 4 + 16) != hipSuccess || pool_alloc(&b->d_dbg_q, per * 1024 * 2 + 16) != hipSuccess ||
+        pool_alloc(&b->d_dbg_sfw, per * 25 * 2 + 16) != hipSuccess)
         return done(fail(c, FLO_ERR_NOMEM, "hipMalloc analysis buffers"));
     if (in_coeffs) {
         if (hipMalloc(&d_in, per * 1024 * 4) != hipSuccess) return done(fail(c, FLO_ERR_NOMEM, "hipMalloc"));
@@ -938,7 +1122,7 @@ namespace {
 struct DevMem {   // frees on scope exit
     void *p = nullptr;
     ~DevMem() {
-        if (p) hipFree(p);
+        if (p) pool_free(p);   // the owner has synchronised the stream by the time this runs
     }
     template <class T>
     T *as() const { return reinterpret_cast<T *>(p); }
@@ -946,7 +1130,7 @@ struct DevMem {   // frees on scope exit
 template <class T>
 int upload(flo_ctx *c, DevMem &m, const std::vector<T> &v) {
     size_t bytes = v.size() * sizeof(T);
-    HIPCHK(c, hipMalloc(&m.p, bytes ? bytes : 16));
+    HIPCHK(c, pool_alloc(&m.p, bytes ? bytes : 16));
     if (bytes) HIPCHK(c, hipMemcpyAsync(m.p, v.data(), bytes, hipMemcpyHostToDevice, c->stream));
     return FLO_OK;
 }
@@ -994,7 +1178,7 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
     if (channels) *channels = f.channels;
     const int nch = f.channels;
     DevMem d_bytes;
-    HIPCHK(c, hipMalloc(&d_bytes.p, len + 32));
+    HIPCHK(c, pool_alloc(&d_bytes.p, len + 32));
     HIPCHK(c, hipMemcpyAsync(d_bytes.p, flo, len, hipMemcpyHostToDevice, c->stream));
 
     if (f.is_transform) {
@@ -1032,7 +1216,7 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
                 free(host);
                 return rc;
             }
-            hipError_t e = hipMalloc(&d_out.p, n_out ? n_out * sizeof(float) : 16);
+            hipError_t e = pool_alloc(&d_out.p, n_out ? n_out * sizeof(float) : 16);
             if (e == hipSuccess && n_out) e = hipMemsetAsync(d_out.p, 0, n_out * sizeof(float), c->stream);
             if (e != hipSuccess) {
                 free(host);
@@ -1114,13 +1298,13 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
         DevMem d_ch, d_fr, d_scr, d_out, d_outi;
         int rc;
         if ((rc = upload(c, d_ch, chs)) || (rc = upload(c, d_fr, frs))) return bail(rc);
-        hipError_t e = hipMalloc(&d_scr.p, scratch ? scratch * sizeof(int) : 16);
+        hipError_t e = pool_alloc(&d_scr.p, scratch ? scratch * sizeof(int) : 16);
         if (e == hipSuccess && host) {
-            e = hipMalloc(&d_out.p, n_out * sizeof(float));
+            e = pool_alloc(&d_out.p, n_out * sizeof(float));
             if (e == hipSuccess) e = hipMemsetAsync(d_out.p, 0, n_out * sizeof(float), c->stream);
         }
         if (e == hipSuccess && host_i) {
-            e = hipMalloc(&d_outi.p, n_out * sizeof(int));
+            e = pool_alloc(&d_outi.p, n_out * sizeof(int));
             if (e == hipSuccess) e = hipMemsetAsync(d_outi.p, 0, n_out * sizeof(int), c->stream);
         }
         if (e != hipSuccess) return bail(fail(c, FLO_ERR_NOMEM, std::string("decode buffers: ") + hipGetErrorString(e)));

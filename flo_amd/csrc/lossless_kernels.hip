@@ -23,6 +23,7 @@
 
 #include "container.hpp"
 #include "lossless_kernels.hpp"
+#include "devpool.hpp"
 
 #include "container_kernels.hpp"
 
@@ -946,7 +947,7 @@ void lossless_plan_destroy(LosslessPlan *p) {
     void *ptrs[] = {p->d_frames, p->d_fout, p->d_chans, p->d_planes, p->d_cff, p->d_coo, p->d_clip_bytes, p->d_out,
                     p->d_cf0, p->d_fsize, p->d_fsamp, p->d_cfn, p->d_crc, p->d_part};
     for (void *q : ptrs)
-        if (q) (void)hipFree(q);
+        if (q) pool_free(q);
     delete p;
 }
 
@@ -1005,14 +1006,14 @@ LosslessPlan *lossless_plan_create(const std::vector<uint64_t> &n_il, const std:
         return nullptr;                                                 \
     }
     const size_t nf = p->frames.size();
-    LCHK(hipMalloc(&p->d_frames, (nf + 1) * sizeof(LLFrame)));
-    LCHK(hipMalloc(&p->d_fout, (nf + 1) * sizeof(LLFrameOut)));
-    LCHK(hipMalloc(&p->d_chans, (p->n_chans + 1) * sizeof(LLChan)));
-    LCHK(hipMalloc(&p->d_planes, (planes + 4) * sizeof(int)));
-    LCHK(hipMalloc(&p->d_cff, (p->n_clips + 1) * 4));
-    LCHK(hipMalloc(&p->d_coo, (p->n_clips + 1) * 8));
-    LCHK(hipMalloc(&p->d_clip_bytes, (p->n_clips + 1) * 8));
-    LCHK(hipMalloc(&p->d_out, out + 64));
+    LCHK(pool_alloc(&p->d_frames, (nf + 1) * sizeof(LLFrame)));
+    LCHK(pool_alloc(&p->d_fout, (nf + 1) * sizeof(LLFrameOut)));
+    LCHK(pool_alloc(&p->d_chans, (p->n_chans + 1) * sizeof(LLChan)));
+    LCHK(pool_alloc(&p->d_planes, (planes + 4) * sizeof(int)));
+    LCHK(pool_alloc(&p->d_cff, (p->n_clips + 1) * 4));
+    LCHK(pool_alloc(&p->d_coo, (p->n_clips + 1) * 8));
+    LCHK(pool_alloc(&p->d_clip_bytes, (p->n_clips + 1) * 8));
+    LCHK(pool_alloc(&p->d_out, out + 64));
     if (nf) LCHK(hipMemcpy(p->d_frames, p->frames.data(), nf * sizeof(LLFrame), hipMemcpyHostToDevice));
     LCHK(hipMemcpy(p->d_cff, p->clip_first_frame.data(), (p->n_clips + 1) * 4, hipMemcpyHostToDevice));
     if (p->n_clips) LCHK(hipMemcpy(p->d_coo, p->clip_out_off.data(), p->n_clips * 8, hipMemcpyHostToDevice));
@@ -1024,12 +1025,12 @@ LosslessPlan *lossless_plan_create(const std::vector<uint64_t> &n_il, const std:
             cfn[i] = p->clip_first_frame[i + 1] - p->clip_first_frame[i];
         }
         for (size_t f = 0; f < nf; f++) fsamp[f] = p->frames[f].frame_samples;
-        LCHK(hipMalloc(&p->d_cf0, cf0.size() * 8));
-        LCHK(hipMalloc(&p->d_cfn, cfn.size() * 4));
-        LCHK(hipMalloc(&p->d_fsamp, fsamp.size() * 4));
-        LCHK(hipMalloc(&p->d_fsize, (nf + 1) * 4));
-        LCHK(hipMalloc(&p->d_crc, (p->n_clips + 1) * 4));
-        LCHK(hipMalloc(&p->d_part, (p->n_clips * finish_parts_for(p->n_clips) + 1) * 4));
+        LCHK(pool_alloc(&p->d_cf0, cf0.size() * 8));
+        LCHK(pool_alloc(&p->d_cfn, cfn.size() * 4));
+        LCHK(pool_alloc(&p->d_fsamp, fsamp.size() * 4));
+        LCHK(pool_alloc(&p->d_fsize, (nf + 1) * 4));
+        LCHK(pool_alloc(&p->d_crc, (p->n_clips + 1) * 4));
+        LCHK(pool_alloc(&p->d_part, (p->n_clips * finish_parts_for(p->n_clips) + 1) * 4));
         LCHK(hipMemcpy(p->d_cf0, cf0.data(), cf0.size() * 8, hipMemcpyHostToDevice));
         LCHK(hipMemcpy(p->d_cfn, cfn.data(), cfn.size() * 4, hipMemcpyHostToDevice));
         LCHK(hipMemcpy(p->d_fsamp, fsamp.data(), fsamp.size() * 4, hipMemcpyHostToDevice));

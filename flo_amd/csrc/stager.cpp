@@ -1,0 +1,233 @@
+// stager.cpp — see stager.hpp
+#include "stager.hpp"
+
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+namespace flo {
+
+namespace {
+constexpr size_t kSlotBytes = (size_t)8 << 20;   // ring slot
+constexpr int kSlots = 4;
+constexpr size_t kPiece = (size_t)512 << 10;     // unit of work handed to a worker thread
+constexpr size_t kSmallUpload = (size_t)12 << 20;
+}  // namespace
+
+class Stager {
+   public:
+    struct Job {
+        char *dst;
+        const char *src;
+        size_t bytes;
+    };
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<Job> jobs;
+    size_t next_job = 0;
+    size_t done_jobs = 0;
+    bool quit = false;
+    char *slot[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_used[kSlots] = {false, false, false, false};
+    int cur = 0;
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    struct PinBlock {
+        void *p = nullptr;
+        size_t cap = 0;
+        bool in_use = false;
+    };
+    std::vector<PinBlock> blocks;   // pinned download buffers, kept for the next call
+
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] { return quit || next_job < jobs.size(); });
+            if (quit) return;
+            while (next_job < jobs.size()) {
+                const Job j = jobs[next_job++];
+                lk.unlock();
+                memcpy(j.dst, j.src, j.bytes);
+                lk.lock();
+                if (++done_jobs == jobs.size()) cv_done.notify_all();
+            }
+        }
+    }
+    // run the queued jobs on the workers and on the calling thread; returns when all are done
+    void run(std::vector<Job> &&js) {
+        if (js.empty()) return;
+        if (js.size() == 1 || workers.empty()) {
+            for (const Job &j : js) memcpy(j.dst, j.src, j.bytes);
+            return;
+        }
+        std::unique_lock<std::mutex> lk(mu);
+        jobs = std::move(js);
+        next_job = 0;
+        done_jobs = 0;
+        cv_work.notify_all();
+        while (next_job < jobs.size()) {   // the caller works too
+            const Job j = jobs[next_job++];
+            lk.unlock();
+            memcpy(j.dst, j.src, j.bytes);
+            lk.lock();
+            ++done_jobs;
+        }
+        cv_done.wait(lk, [&] { return done_jobs == jobs.size(); });
+        jobs.clear();
+        next_job = done_jobs = 0;
+    }
+};
+
+Stager *stager_create(std::string &err) {
+    (void)err;
+    return new Stager();   // the ring and the copy threads are made by the first large upload
+}
+
+static bool ensure_ring(Stager *s, std::string &err) {
+    if (s->slot[0]) return true;
+    for (int i = 0; i < kSlots; i++) {
+        if (hipHostMalloc((void **)&s->slot[i], kSlotBytes) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming) != hipSuccess) {
+            err = "pinned staging ring: allocation failed";
+            return false;
+        }
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = hw > 2 ? (int)(hw - 1) : 1;
+    if (n > 5) n = 5;   // with the caller: six copying threads (four already reach the PCIe rate; more only add scheduler noise)
+    for (int i = 0; i < n; i++) s->workers.emplace_back([s] { s->worker(); });
+    return true;
+}
+
+void stager_destroy(Stager *s) {
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->quit = true;
+    }
+    s->cv_work.notify_all();
+    for (auto &t : s->workers) t.join();
+    for (int i = 0; i < kSlots; i++) {
+        if (s->ev[i]) {
+            if (s->ev_used[i]) hipEventSynchronize(s->ev[i]);
+            hipEventDestroy(s->ev[i]);
+        }
+        if (s->slot[i]) hipHostFree(s->slot[i]);
+    }
+    if (s->pinned) hipHostFree(s->pinned);
+    for (auto &b : s->blocks) hipHostFree(b.p);
+    delete s;
+}
+
+void *stager_pinned_get(Stager *s, size_t bytes, std::string &err) {
+    for (auto &b : s->blocks)
+        if (!b.in_use && b.cap >= bytes) {
+            b.in_use = true;
+            return b.p;
+        }
+    Stager::PinBlock nb;
+    nb.cap = bytes + bytes / 4 + 65536;
+    if (hipHostMalloc(&nb.p, nb.cap) != hipSuccess) {
+        err = "pinned download buffer: allocation failed";
+        return nullptr;
+    }
+    nb.in_use = true;
+    s->blocks.push_back(nb);
+    return nb.p;
+}
+void stager_pinned_put(Stager *s, void *p) {
+    for (auto &b : s->blocks)
+        if (b.p == p) b.in_use = false;
+}
+
+void *stager_pinned(Stager *s, size_t bytes, std::string &err) {
+    if (s->pinned_bytes >= bytes && s->pinned) return s->pinned;
+    if (s->pinned) hipHostFree(s->pinned);
+    s->pinned = nullptr;
+    s->pinned_bytes = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&s->pinned, want) != hipSuccess) {
+        err = "pinned download buffer: allocation failed";
+        return nullptr;
+    }
+    s->pinned_bytes = want;
+    return s->pinned;
+}
+
+void stager_memcpy_many(Stager *s, const std::vector<UploadSeg> &segs) {
+    std::vector<Stager::Job> js;
+    for (const UploadSeg &g : segs)
+        for (size_t o = 0; o < g.bytes; o += kPiece)
+            js.push_back({(char *)g.dst + o, (const char *)g.src + o, g.bytes - o < kPiece ? g.bytes - o : kPiece});
+    s->run(std::move(js));
+}
+
+int stager_upload(Stager *s, const std::vector<UploadSeg> &segs, hipStream_t stream, std::string &err) {
+    // a few megabytes: waking the copy threads costs more than they save; the runtime's own pageable path is used
+    size_t total = 0;
+    for (const UploadSeg &g : segs) total += g.bytes;
+    if (total <= kSmallUpload) {
+        for (const UploadSeg &g : segs)
+            if (g.bytes && hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, stream) != hipSuccess) {
+                err = "hipMemcpyAsync (upload) failed";
+                return -1;
+            }
+        return 0;
+    }
+    if (!ensure_ring(s, err)) return -1;
+    // walk the segments, cutting them at ring-slot boundaries: a slot is filled by the worker threads, then handed to
+    // the copy engine (one asynchronous copy per piece of a segment), while the next slot is being filled
+    size_t si = 0, so = 0;   // current segment and offset inside it
+    while (si < segs.size()) {
+        const int k = s->cur;
+        s->cur = (s->cur + 1) % kSlots;
+        if (s->ev_used[k] && hipEventSynchronize(s->ev[k]) != hipSuccess) {
+            err = "staging ring: event wait failed";
+            return -1;
+        }
+        std::vector<Stager::Job> js;
+        struct Out {
+            void *dst;
+            size_t off, bytes;
+        };
+        std::vector<Out> outs;
+        size_t fill = 0;
+        while (si < segs.size() && fill < kSlotBytes) {
+            const UploadSeg &g = segs[si];
+            if (g.bytes == so) {   // empty or finished segment
+                si++;
+                so = 0;
+                continue;
+            }
+            size_t n = g.bytes - so;
+            if (n > kSlotBytes - fill) n = kSlotBytes - fill;
+            outs.push_back({(char *)g.dst + so, fill, n});
+            for (size_t o = 0; o < n; o += kPiece)
+                js.push_back({s->slot[k] + fill + o, (const char *)g.src + so + o, n - o < kPiece ? n - o : kPiece});
+            fill += (n + 63) & ~(size_t)63;
+            so += n;
+            if (so == g.bytes) {
+                si++;
+                so = 0;
+            }
+        }
+        s->run(std::move(js));
+        for (const Out &o : outs)
+            if (hipMemcpyAsync(o.dst, s->slot[k] + o.off, o.bytes, hipMemcpyHostToDevice, stream) != hipSuccess) {
+                err = "staging ring: hipMemcpyAsync failed";
+                return -1;
+            }
+        if (hipEventRecord(s->ev[k], stream) != hipSuccess) {
+            err = "staging ring: event record failed";
+            return -1;
+        }
+        s->ev_used[k] = true;
+    }
+    return 0;
+}
+
+}  // namespace flo

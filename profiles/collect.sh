@@ -8,10 +8,10 @@ tag=${1:-r02}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-BENCH="bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-e2e"
 rocprofv3 --kernel-trace --stats -d $out/stats -o run --output-format csv -- python $BENCH > $out/stats.log 2>&1
 tail -n 1 $out/stats.log > /dev/null
-SHORT="bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-single-clip"
+SHORT="bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --no-single-clip"
 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o run --output-format csv -- python $SHORT > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $out/write -o run --output-format csv -- python $SHORT > $out/write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE \
