@@ -245,6 +245,7 @@ static int get_tables(flo_ctx *c, uint32_t sr, float quality, TableSet **out) {
         total += b;
         return parts.size() - 1;
     };
+    size_t i_ext = add(h.pack_ext.data(), h.pack_ext.size() * 4);
     size_t i_pack = add(h.pack.data(), h.pack.size() * 4), i_athdb = add(h.ath_db.data(), h.ath_db.size() * 4),
            i_band = add(h.band.data(), h.band.size()), i_bc = add(h.band_count.data(), h.band_count.size() * 4),
            i_s10 = add(h.s10d.data(), h.s10d.size() * 4), i_lb = add(h.lane_bnd.data(), h.lane_bnd.size() * 4),
@@ -265,6 +266,7 @@ static int get_tables(flo_ctx *c, uint32_t sr, float quality, TableSet **out) {
     }
     auto P = [&](size_t i) { return (const char *)t->blob + parts[i].off; };
     t->dev.pack = (const float4 *)P(i_pack);
+    t->dev.pack_ext = (const float4 *)P(i_ext);
     t->dev.ath_db = (const float *)P(i_athdb);
     t->dev.band = (const uint8_t *)P(i_band);
     t->dev.band_count = (const float *)P(i_bc);
@@ -276,7 +278,7 @@ static int get_tables(flo_ctx *c, uint32_t sr, float quality, TableSet **out) {
     t->dev.max_band_slots = h.max_band_slots;
     t->dev.smr_thr = h.smr_threshold;
     t->dev.q_transparent = h.q_transparent;
-    if (h.n_slots > kSlotCap || h.max_band_slots > 48) {
+    if (h.n_slots > kSlotCap || h.max_band_slots > 64) {   // (cannot happen: 64 lanes + 24 band edges, 64 lanes per band)
         hipFree(t->blob);
         delete t;
         return fail(c, FLO_ERR_ARG, "band segment table exceeds capacity");

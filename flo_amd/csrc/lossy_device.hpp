@@ -37,6 +37,7 @@ constexpr int kPackRows = 46;
 
 struct LossyDevTables {
     const float4 *pack;      // [kPackRows][64]
+    const float4 *pack_ext;  // [2][64] slot-list groups 6, 7 (global memory; sample rates from 128 kHz up)
     const float *ath_db;     // [1024]
     const uint8_t *band;     // [1024]
     const float *band_count; // [25]
@@ -656,7 +657,7 @@ __device__ __forceinline__ void band_stats(const int lane, const float (&c)[CH][
         }
     const int groups = (T.max_band_slots + 7) >> 3;  // 4 list entries per group, each lane takes every other slot
     for (int g = 3; g < groups; g++) {
-        const float4 lst = T.pack[(39 + g) * 64 + lane];
+        const float4 lst = g < 6 ? T.pack[(39 + g) * 64 + lane] : T.pack_ext[(g - 6) * 64 + lane];
         const uint32_t sx[4] = {__float_as_uint(lst.x), __float_as_uint(lst.y), __float_as_uint(lst.z), __float_as_uint(lst.w)};
         float2 vx[CH][4];
 #pragma unroll
@@ -862,7 +863,7 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
     bmax = splat2(0.f);
     const int groups = (T.max_band_slots + 7) >> 3;
     for (int g = 0; g < (groups < 3 ? 3 : groups); g++) {
-        const float4 lst = T.pack[(39 + g) * 64 + lane];
+        const float4 lst = g < 6 ? T.pack[(39 + g) * 64 + lane] : T.pack_ext[(g - 6) * 64 + lane];
         const uint32_t so[4] = {__float_as_uint(lst.x), __float_as_uint(lst.y), __float_as_uint(lst.z), __float_as_uint(lst.w)};
         float2 vs[4], vm[4];
 #pragma unroll

@@ -109,6 +109,7 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
 
     // per-lane constant pack [row][lane][4] (layout documented in lossy_device.hpp)
     t.pack.assign(46 * 64 * 4, 0.0f);
+    t.pack_ext.assign(2 * 64 * 4, 0.0f);
     auto P = [&](int row, int lane, int i) -> float & { return t.pack[((size_t)row * 64 + lane) * 4 + i]; };
     // row 45 is not per lane: its first 24 floats are s10d[1..24], read uniformly by every lane
     for (int d = 1; d < kNumBands; d++) P(45, (d - 1) / 4, (d - 1) % 4) = t.s10d[d];
@@ -202,6 +203,13 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
         for (int u = 0; u < 24; u++) {
             const uint32_t sidx = bs0 + 2u * (uint32_t)u;
             PU(39 + u / 4, lane, u % 4, (sidx < bs1 ? sidx : (uint32_t)(kSlotCapHost + 64)) * 8u);
+        }
+        // entries 24..31 (a band can span all 64 lanes: 32 slots per reducer lane) live outside the LDS pack: only the
+        // widest band of sample rates from 128 kHz up reaches them, and the kernels read them from global memory
+        for (int u = 24; u < 32; u++) {
+            const uint32_t sidx = bs0 + 2u * (uint32_t)u;
+            const uint32_t v = (sidx < bs1 ? sidx : (uint32_t)(kSlotCapHost + 64)) * 8u;
+            memcpy(&t.pack_ext[((size_t)((u - 24) / 4) * 64 + lane) * 4 + u % 4], &v, 4);
         }
         PU(26, lane, 0, t.lane_bnd[lane]);
         PU(26, lane, 1, t.lane_slot0[lane]);

@@ -21,6 +21,9 @@
  * thread / GPU; contexts are independent. A "fresh encoder per clip" is the contract for lossy encodes
  * (the reference never resets the psychoacoustic state between calls; all its callers build a new encoder).
  *
+ * Sample rates: any rate the reference accepts (tested 8 kHz .. 384 kHz for lossy encode and decode, 8 .. 192 kHz
+ * lossless); channels: 1 .. 8 lossy, 1 .. 255 lossless.
+ *
  * There is NO CPU fallback: every encode and decode entry point runs the HIP kernels on the context's device and
  * fails with a non-zero code if no gfx950 device is usable.
  */

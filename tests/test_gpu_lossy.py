@@ -193,7 +193,7 @@ def test_analyze_parity(ctx, ch, q):
     ctx.force_path(0)
 
 
-@pytest.mark.parametrize("sr", [8000, 22050, 48000, 96000])
+@pytest.mark.parametrize("sr", [8000, 22050, 48000, 96000, 128000, 176400, 192000, 384000])
 def test_other_sample_rates(ctx, sr):
     pcm = signals.music_like(sr, 20000, 2, seed=sr)
     o = O.lossy_analyze(pcm, sr, 2, 0.55)
@@ -201,6 +201,13 @@ def test_other_sample_rates(ctx, sr):
     ctx.force_path(4)          # the lock-step stereo form has its own band-statistics code: other band tables too
     compare_lossy_stage(ctx.lossy_analyze(pcm, sr, 2, 0.55), o, sr, tag="path4")
     ctx.force_path(0)
+    # the whole drop-in call and the decode at this rate (from 128 kHz up band 24 spans more than 48 lane segments)
+    flo = ctx.encode_lossy(pcm, sr, 2, 0.55)
+    fo = O.encode_lossy(pcm, sr, 2, 0.55)
+    same_structure(flo, fo)
+    dec = ctx.decode(fo)
+    odec = O.decode(fo)[0]
+    assert dec.shape == odec.shape and float(np.max(np.abs(dec - odec))) <= 4e-6
 
 
 def test_chain_and_frame_parallel_forms_give_identical_files(ctx):
