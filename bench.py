@@ -300,9 +300,24 @@ def main():
             bl.encode(0)
             bl.sync()
         d4 = (time.perf_counter() - t4) / reps
+        lsamples = lsr * lsec * ch * lclips
+        lbytes = bl.data_bytes()
+        # Rooflines of the lossless path. It is neither HBM- nor multiplier-bound: the level-5 search costs 35 i64
+        # multiply-adds per sample (autocorrelation lags 0..8 + LPC orders 5..8 once each; lpc.rs:213-221,279-298), the
+        # chip sustains 11.6 T of them per second (diag/mad64_rate.hip, 4 waves per SIMD), and the algorithmic HBM
+        # traffic is 4 B in + the emitted bytes; both fractions are reported, the kernels are instruction-issue bound
+        # (5.4 vector + 2 scalar wave-instructions per sample, profiles/).
+        mads_per_sample, mad_peak = 35.0, 11.6e12
         out["lossless_96k"] = {"workload": f"{lclips} x {lsec} s 96 kHz stereo clips, lossless level 5 (BASELINE configs[4] shape)",
-                               "value": round(lsr * lsec * ch * lclips / d4 / 1e6, 1), "unit": "Msamples/s", "ms": round(d4 * 1e3, 3),
-                               "compressed_bytes": bl.data_bytes()}
+                               "value": round(lsamples / d4 / 1e6, 1), "unit": "Msamples/s", "ms": round(d4 * 1e3, 3),
+                               "compressed_bytes": lbytes,
+                               "roofline": {"bound": "instruction issue (int64 multiply-add search)",
+                                            "i64_mads_per_sample": mads_per_sample,
+                                            "achieved_Tmad_s": round(mads_per_sample * lsamples / d4 / 1e12, 3),
+                                            "peak_Tmad_s_measured": mad_peak / 1e12,
+                                            "frac_of_i64_mad_peak": round(mads_per_sample * lsamples / d4 / mad_peak, 4),
+                                            "hbm_algorithmic_GBs": round((4.0 * lsamples + lbytes) / d4 / 1e9, 1),
+                                            "frac_of_hbm_peak": round((4.0 * lsamples + lbytes) / d4 / 1e9 / HBM_PEAK_GBS, 4)}}
         bl.close()
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as O
