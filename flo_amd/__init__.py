@@ -4,5 +4,5 @@ The compute path is flo_amd/libflo_hip.so (hand-written gfx950 HIP kernels behin
 this package is only the host-side mirror of the reference's encoder interface.
 """
 from ._native import FloError, MODE_LOSSLESS, MODE_LOSSY  # noqa: F401
-from .api import (Batch, Context, Decoder, Encoder, LossyEncoder, QualityPreset, TransformEncoder, default_context,  # noqa: F401
-                  decode, encode, encode_lossy, encode_with_bitrate, probe_container)
+from .api import (Batch, Context, Decoder, EncodedFrame, Encoder, LossyEncoder, QualityPreset, StreamingEncoder,  # noqa: F401
+                  TransformEncoder, default_context, decode, encode, encode_lossy, encode_with_bitrate, probe_container)

@@ -26,6 +26,8 @@ EXPORTS = [
     "flo_mdct_forward", "flo_lossy_analyze", "flo_lossy_quantize", "flo_sparse_pack",
     "flo_dist_unique_id", "flo_dist_create", "flo_dist_destroy", "flo_dist_gather_submit", "flo_dist_gather_flush",
     "flo_dist_gather_result", "flo_dist_stream",
+    "flo_stream_create", "flo_stream_destroy", "flo_stream_push", "flo_stream_pending_samples", "flo_stream_pending_frames",
+    "flo_stream_next_frame", "flo_stream_flush", "flo_stream_finalize",
 ]
 
 
@@ -108,6 +110,18 @@ def lib():
     L.flo_dist_gather_result.argtypes = [vp, C.POINTER(vp), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint64))]
     L.flo_dist_stream.argtypes = [vp]
     L.flo_dist_stream.restype = vp
+    u32p = C.POINTER(C.c_uint32)
+    L.flo_stream_create.argtypes = [vp, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint8, C.POINTER(vp)]
+    L.flo_stream_destroy.argtypes = [vp]
+    L.flo_stream_destroy.restype = None
+    L.flo_stream_push.argtypes = [vp, vp, sz]
+    L.flo_stream_pending_samples.argtypes = [vp]
+    L.flo_stream_pending_samples.restype = sz
+    L.flo_stream_pending_frames.argtypes = [vp]
+    L.flo_stream_pending_frames.restype = sz
+    L.flo_stream_next_frame.argtypes = [vp, u32p, u32p, u32p, C.POINTER(vp), C.POINTER(sz)]
+    L.flo_stream_flush.argtypes = L.flo_stream_next_frame.argtypes
+    L.flo_stream_finalize.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp), C.POINTER(sz)]
     L.flo_decode.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
     L.flo_decode_lossless_i32.argtypes = L.flo_decode.argtypes
     L.flo_probe_container.argtypes = [C.c_char_p, sz, C.POINTER(ContainerInfo), C.c_char_p, sz]

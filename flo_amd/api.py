@@ -348,6 +348,82 @@ class TransformEncoder:
 LossyEncoder = TransformEncoder
 
 
+class EncodedFrame:
+    """streaming/encoder.rs:18-29"""
+
+    def __init__(self, index, timestamp_ms, data, samples):
+        self.index, self.timestamp_ms, self.data, self.samples = index, timestamp_ms, data, samples
+
+    def __repr__(self):
+        return f"EncodedFrame(index={self.index}, timestamp_ms={self.timestamp_ms}, samples={self.samples}, {len(self.data)} bytes)"
+
+
+class StreamingEncoder:
+    """streaming::StreamingEncoder - libflo/src/streaming/encoder.rs:6-257, over flo_stream_* of the C ABI."""
+
+    def __init__(self, sample_rate: int, channels: int, bit_depth: int, ctx: Context = None):
+        self.sample_rate, self.channels, self.bit_depth = sample_rate, channels, bit_depth
+        self.compression_level = 5
+        self._ctx = ctx or default_context()
+        self._L = self._ctx._L
+        self._h = None
+        self._open()
+
+    def _open(self):
+        if self._h:
+            self._L.flo_stream_destroy(self._h)
+        h = C.c_void_p()
+        self._ctx._chk(self._L.flo_stream_create(self._ctx._h, self.sample_rate, self.channels, self.bit_depth, self.compression_level, C.byref(h)))
+        self._h = h
+
+    def with_compression(self, level: int) -> "StreamingEncoder":
+        self.compression_level = min(int(level), 9)
+        self._open()      # like the reference, meant to be called right after construction
+        return self
+
+    def pending_samples(self) -> int:
+        return self._L.flo_stream_pending_samples(self._h)
+
+    def pending_frames(self) -> int:
+        return self._L.flo_stream_pending_frames(self._h)
+
+    def push_samples(self, samples):
+        p = _f32(samples)
+        self._ctx._chk(self._L.flo_stream_push(self._h, p.ctypes.data, p.size))
+
+    def _pull(self, fn):
+        idx, ts, ns = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        data, n = C.c_void_p(), C.c_size_t()
+        r = fn(self._h, C.byref(idx), C.byref(ts), C.byref(ns), C.byref(data), C.byref(n))
+        if r < 0:
+            raise FloError(self._L.flo_last_error(self._ctx._h).decode())
+        if r == 0:
+            return None
+        return EncodedFrame(idx.value, ts.value, self._ctx._take(data, n), ns.value)
+
+    def next_frame(self):
+        return self._pull(self._L.flo_stream_next_frame)
+
+    def flush(self):
+        return self._pull(self._L.flo_stream_flush)
+
+    def finalize(self, metadata: bytes = b"") -> bytes:
+        out, n = C.c_void_p(), C.c_size_t()
+        self._ctx._chk(self._L.flo_stream_finalize(self._h, metadata, len(metadata), C.byref(out), C.byref(n)))
+        return self._ctx._take(out, n)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.flo_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def probe_container(data: bytes):
     """Header and frame census of a .flo file as the container reader sees it (reader.rs:16-256); no device needed.
     Raises FloError with the reader's message for files the reference reader rejects."""

@@ -1,0 +1,150 @@
+"""A `reflo`-shaped command line on top of the HIP library (python -m flo_amd.cli ...).
+
+Mirrors the reference CLI (reflo/src/main.rs:19-93, 218-420): the same sub-commands, options, quality names and
+printed fields for the parts that sit on this repository's path -
+    encode  <in.wav> <out.flo> [--level N] [--lossy | --transform] [--quality low|medium|high|veryhigh|transparent]
+                               [--bitrate KBPS]
+    decode  <in.flo> <out.wav>
+    info    <in.flo>
+    validate <in.flo>
+Ingestion is WAV only (flo_amd/wav.py; the reference demuxes MP3/FLAC/OGG/AAC through symphonia, reflo/src/audio.rs:57-166).
+Files are written without a META chunk: the reference CLI embeds encoder/source metadata and analysis data as
+MessagePack (reflo/src/lib.rs:202-283), which is not part of this repository's path (out of scope), so the
+--title / --artist / --album options and the `metadata` / `analysis` sub-commands are not offered.
+The quality names map as in the reference CLI (main.rs:236-242): low 0.2, medium 0.4, high 0.6, veryhigh 0.8,
+transparent 1.0 - NOT the QualityPreset values the library API uses (lossy/mod.rs:39-47).
+"""
+import argparse
+import sys
+
+from . import api
+from .wav import WavError, read_wav_bytes, write_wav_bytes
+
+QUALITY = {"low": 0.2, "medium": 0.4, "med": 0.4, "high": 0.6, "veryhigh": 0.8, "vh": 0.8, "transparent": 1.0, "trans": 1.0}
+QUALITY_NAMES = ["Low", "Medium", "High", "VeryHigh", "Transparent"]
+
+
+def encode_from_audio(audio_bytes: bytes, level=5, lossy=False, quality=0.6, bitrate=None, ctx=None) -> bytes:
+    """reflo::encode_from_audio (reflo/src/lib.rs:183-306) for WAV input, without the metadata step."""
+    samples, sr, ch = read_wav_bytes(audio_bytes)
+    c = ctx or api.default_context()
+    if lossy or bitrate is not None:
+        q = api.QualityPreset.from_bitrate(bitrate, sr, ch).as_f32() if bitrate is not None else min(max(float(quality), 0.0), 1.0)
+        return api.TransformEncoder(sr, ch, q, c).encode_to_flo(samples, b"")
+    return api.Encoder(sr, ch, 16, c).with_compression(min(int(level), 9)).encode(samples, b"")
+
+
+def decode_to_wav(flo_bytes: bytes, ctx=None) -> bytes:
+    """reflo::decode_to_wav: libflo::decode, then a 32-bit float WAV (reflo/src/audio.rs:290-320)."""
+    c = ctx or api.default_context()
+    pcm, sr, ch = c.decode(flo_bytes, with_info=True)
+    return write_wav_bytes(pcm, sr, ch)
+
+
+def flo_info(flo_bytes: bytes) -> dict:
+    """reflo::get_flo_info (reflo/src/lib.rs:40-93): header fields, duration, compression ratio, CRC check."""
+    import zlib
+    i = api.probe_container(flo_bytes)
+    data = flo_bytes[i.data_start:i.data_start + i.data_size]
+    duration = i.total_samples / i.sample_rate if i.sample_rate else 0.0
+    raw = i.total_samples * i.channels * (i.bit_depth // 8)
+    return dict(version=f"{i.version_major}.{i.version_minor}", sample_rate=i.sample_rate, channels=i.channels,
+                bit_depth=i.bit_depth, total_samples=i.total_samples, duration_secs=duration, file_size=len(flo_bytes),
+                compression_ratio=(raw / len(flo_bytes)) if len(flo_bytes) else 0.0,
+                crc_valid=(zlib.crc32(data) & 0xFFFFFFFF) == i.data_crc32, is_lossy=bool(i.flags & 1),
+                lossy_quality=(i.flags >> 8) & 0x0F, compression_level=i.compression_level)
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="flo", description="flo audio format converter (MI355X-native encode / decode)")
+    sub = ap.add_subparsers(dest="command", required=True)
+    e = sub.add_parser("encode", help="Encode a WAV file to flo format")
+    e.add_argument("input")
+    e.add_argument("output")
+    e.add_argument("-l", "--level", type=int, default=5, help="Compression level (0-9, default 5)")
+    e.add_argument("--lossy", action="store_true", help="Enable lossy compression mode")
+    e.add_argument("--transform", action="store_true", help="Use transform-based lossy")
+    e.add_argument("--quality", default="high", help="Lossy quality level (low, medium, high, veryhigh, transparent)")
+    e.add_argument("--bitrate", type=int, default=None, help="Target bitrate in kbps (alternative to quality)")
+    d = sub.add_parser("decode", help="Decode a flo file to WAV")
+    d.add_argument("input")
+    d.add_argument("output")
+    i = sub.add_parser("info", help="Show information about a flo file")
+    i.add_argument("input")
+    v = sub.add_parser("validate", help="Validate a flo file")
+    v.add_argument("input")
+    a = ap.parse_args(argv)
+    try:
+        if a.command == "encode":
+            print(f"Reading {a.input}...")
+            audio = open(a.input, "rb").read()
+            samples, sr, ch = read_wav_bytes(audio)
+            print(f"  Sample rate: {sr} Hz")
+            print(f"  Channels: {ch}")
+            print(f"  Duration: {samples.size / ch / sr:.2f}s")
+            lossy = a.lossy or a.transform
+            if lossy or a.bitrate is not None:
+                if a.bitrate is not None:
+                    print(f"Encoding to flo (lossy, ~{a.bitrate} kbps)...")
+                    q = None
+                else:
+                    if a.quality.lower() not in QUALITY:
+                        print(f"Invalid quality level: {a.quality}. Use: low, medium, high, veryhigh, transparent", file=sys.stderr)
+                        return 1
+                    q = QUALITY[a.quality.lower()]
+                    print(f"Encoding to flo (lossy, {a.quality} quality)...")
+                flo = encode_from_audio(audio, a.level, True, q if q is not None else 0.6, a.bitrate)
+            else:
+                print("Encoding to flo (lossless)...")
+                flo = encode_from_audio(audio, a.level)
+            open(a.output, "wb").write(flo)
+            original = int(samples.size * 4)
+            print("Done!")
+            print(f"  Output: {a.output}")
+            print(f"  Size: {len(flo)} bytes ({original / max(len(flo), 1):.1f}x compression)")
+        elif a.command == "decode":
+            print(f"Reading {a.input}...")
+            flo = open(a.input, "rb").read()
+            info = flo_info(flo)
+            print(f"  Sample rate: {info['sample_rate']} Hz")
+            print(f"  Channels: {info['channels']}")
+            print(f"  Duration: {info['duration_secs']:.2f}s")
+            print("Decoding...")
+            wav = decode_to_wav(flo)
+            print("Writing WAV...")
+            open(a.output, "wb").write(wav)
+            print("Done!")
+            print(f"  Output: {a.output}")
+        elif a.command == "info":
+            info = flo_info(open(a.input, "rb").read())
+            print("flo Audio File")
+            print("-" * 31)
+            print(f"  Version:     {info['version']}")
+            print(f"  Sample rate: {info['sample_rate']} Hz")
+            print(f"  Channels:    {info['channels']}")
+            print(f"  Bit depth:   {info['bit_depth']}")
+            print(f"  Duration:    {info['duration_secs']:.2f}s")
+            print(f"  Total sample-frames: {info['total_samples']}")
+            print(f"  File size:   {info['file_size']} bytes")
+            print(f"  Compression: {info['compression_ratio']:.1f}x")
+            print(f"  CRC valid:   {'yes' if info['crc_valid'] else 'no'}")
+            if info["is_lossy"]:
+                ql = info["lossy_quality"]
+                print(f"  Encoding:    Lossy ({QUALITY_NAMES[ql] if ql < len(QUALITY_NAMES) else 'Unknown'})")
+            else:
+                print("  Encoding:    Lossless")
+        elif a.command == "validate":
+            try:
+                ok = flo_info(open(a.input, "rb").read())["crc_valid"]
+            except api.FloError:
+                ok = False
+            print("Valid flo file" if ok else "Invalid flo file")
+            return 0 if ok else 1
+    except (OSError, WavError, api.FloError) as ex:
+        print(f"Error: {ex}", file=sys.stderr)
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -43,4 +43,8 @@ struct ParsedFile {
 // 0 on success; otherwise `err` holds the reference reader's message ("Invalid flo file: bad magic", ...)
 int parse_file(const uint8_t *data, size_t len, ParsedFile &out, const char **err);
 
+// CRC32 (IEEE, core/crc32.rs:2-30) of host bytes: only the streaming encoder's finalize uses it, for a DATA chunk it
+// assembles on the host from frames the caller may already have pulled (batches compute theirs on the device)
+uint32_t host_crc32(const uint8_t *data, size_t len);
+
 }  // namespace flo

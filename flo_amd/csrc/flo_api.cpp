@@ -1616,3 +1616,221 @@ extern "C" int flo_dist_gather_result(flo_dist *d, const uint8_t **base, const u
 }
 
 extern "C" void *flo_dist_stream(flo_dist *d) { return d ? (void *)d->cs : nullptr; }
+
+// ------------------------------------------------------------------------------------------------ streaming encoder
+// StreamingEncoder of libflo/src/streaming/encoder.rs on the device library: samples are pushed, complete one-second
+// frames are encoded (all frames a push completes go through ONE device batch, where the reference encodes them one
+// after the other through temporary files), frames are pulled or assembled into a file. Frame bytes follow the
+// reference's encode_frame_data / serialize_channel (encoder.rs:215-257) exactly, including its channel layout
+// [rice_parameter][coefficients][residuals], which is not the container writer's.
+struct StreamFrame {
+    uint32_t index, timestamp_ms, samples;
+    std::vector<uint8_t> data;
+};
+struct flo_stream {
+    flo_ctx *ctx = nullptr;
+    uint32_t sr = 0;
+    uint8_t ch = 0, bit_depth = 16, level = 5;
+    std::vector<float> buf;
+    std::vector<StreamFrame> pending;
+    uint64_t total_samples = 0;
+    uint32_t frame_index = 0;
+};
+
+extern "C" int flo_stream_create(flo_ctx *c, uint32_t sample_rate, uint8_t channels, uint8_t bit_depth, uint8_t level,
+                                 flo_stream **out) {
+    if (!c || !out) return FLO_ERR_ARG;
+    *out = nullptr;
+    if (!sample_rate || !channels) return fail(c, FLO_ERR_ARG, "sample_rate and channels must be non-zero");
+    flo_stream *s = new flo_stream();
+    s->ctx = c;
+    s->sr = sample_rate;
+    s->ch = channels;
+    s->bit_depth = bit_depth;
+    s->level = level > 9 ? 9 : level;   // with_compression: level.min(9) (encoder.rs:51-56)
+    *out = s;
+    return FLO_OK;
+}
+extern "C" void flo_stream_destroy(flo_stream *s) { delete s; }
+extern "C" size_t flo_stream_pending_samples(const flo_stream *s) { return s ? s->buf.size() / s->ch : 0; }
+extern "C" size_t flo_stream_pending_frames(const flo_stream *s) { return s ? s->pending.size() : 0; }
+
+// encode_frame_data for `count` chunks of `per` interleaved samples starting at `src` (encoder.rs:215-241): one
+// lossless batch, then every one-frame file is parsed like Reader::read and its first frame re-serialised
+static int stream_encode_chunks(flo_stream *s, const float *src, size_t count, size_t per, std::vector<std::vector<uint8_t>> &frames) {
+    flo_ctx *c = s->ctx;
+    frames.clear();
+    if (!count) return FLO_OK;
+    std::vector<size_t> n_il(count, per);
+    flo_batch *b = nullptr;
+    int rc = flo_batch_create(c, FLO_MODE_LOSSLESS, count, n_il.data(), s->sr, s->ch, (float)s->level, &b);
+    if (rc != FLO_OK) return rc;
+    b->bit_depth = s->bit_depth;
+    std::vector<const float *> ptrs(count);
+    for (size_t i = 0; i < count; i++) ptrs[i] = src + i * per;
+    rc = batch_upload_all(b, ptrs.data());
+    if (rc == FLO_OK) rc = flo_batch_encode(b, 0);
+    if (rc == FLO_OK) rc = flo_batch_sync(b);
+    for (size_t i = 0; i < count && rc == FLO_OK; i++) {
+        uint8_t *file = nullptr;
+        size_t flen = 0;
+        rc = flo_batch_fetch(b, i, nullptr, 0, &file, &flen);
+        if (rc != FLO_OK) break;
+        ParsedFile pf;
+        const char *perr = "";
+        if (parse_file(file, flen, pf, &perr) != 0) {
+            free(file);
+            rc = fail(c, FLO_ERR_FORMAT, perr);
+            break;
+        }
+        if (pf.frames.empty()) {
+            free(file);
+            rc = fail(c, FLO_ERR_FORMAT, "No frames encoded");
+            break;
+        }
+        const FrameDesc &fr = pf.frames[0];
+        std::vector<uint8_t> d;
+        auto u32 = [&](uint32_t v) {
+            for (int k = 0; k < 4; k++) d.push_back((uint8_t)(v >> (8 * k)));
+        };
+        d.push_back(fr.type);
+        u32(fr.samples);
+        d.push_back(fr.flags);
+        for (unsigned k = 0; k < fr.n_channels; k++) {
+            const ChannelDesc &cd = pf.channels_desc[fr.first_channel + k];
+            if (fr.type == 0) {                        // Silence: empty
+                u32(0);
+            } else if (fr.type == 254 || fr.type == 253) {   // Raw / Transform: the payload as it is
+                u32(cd.len);
+                d.insert(d.end(), file + cd.off, file + cd.off + cd.len);
+            } else {                                   // every other type: [rice_parameter][coeffs][residuals]
+                u32(1u + 4u * cd.n_coeffs + cd.len);
+                d.push_back(cd.rice_k);
+                for (unsigned q = 0; q < cd.n_coeffs; q++) u32((uint32_t)cd.coeffs[q]);
+                d.insert(d.end(), file + cd.off, file + cd.off + cd.len);
+            }
+        }
+        free(file);
+        frames.push_back(std::move(d));
+    }
+    flo_batch_destroy(b);
+    return rc;
+}
+
+extern "C" int flo_stream_push(flo_stream *s, const float *samples, size_t n) {
+    if (!s || (n && !samples)) return FLO_ERR_ARG;
+    s->buf.insert(s->buf.end(), samples, samples + n);
+    const size_t per = (size_t)s->sr * s->ch;
+    const size_t count = s->buf.size() / per;
+    if (!count) return FLO_OK;
+    std::vector<std::vector<uint8_t>> frames;
+    int rc = stream_encode_chunks(s, s->buf.data(), count, per, frames);
+    if (rc != FLO_OK) return rc;
+    for (size_t i = 0; i < count; i++) {
+        StreamFrame f;
+        f.index = s->frame_index;
+        f.timestamp_ms = (uint32_t)((double)s->total_samples / (double)s->sr * 1000.0);
+        f.samples = s->sr;
+        f.data = std::move(frames[i]);
+        s->pending.push_back(std::move(f));
+        s->total_samples += s->sr;
+        s->frame_index++;
+    }
+    s->buf.erase(s->buf.begin(), s->buf.begin() + count * per);
+    return FLO_OK;
+}
+
+static int stream_hand_out(const StreamFrame &f, uint32_t *index, uint32_t *timestamp_ms, uint32_t *samples, uint8_t **data, size_t *len) {
+    uint8_t *p = (uint8_t *)malloc(f.data.size() ? f.data.size() : 1);
+    if (!p) return -1;
+    memcpy(p, f.data.data(), f.data.size());
+    if (index) *index = f.index;
+    if (timestamp_ms) *timestamp_ms = f.timestamp_ms;
+    if (samples) *samples = f.samples;
+    *data = p;
+    *len = f.data.size();
+    return 0;
+}
+
+// 1: a frame came out (data is malloc'ed, release with flo_free); 0: none ready
+extern "C" int flo_stream_next_frame(flo_stream *s, uint32_t *index, uint32_t *timestamp_ms, uint32_t *samples, uint8_t **data, size_t *len) {
+    if (!s || !data || !len) return -1;
+    if (s->pending.empty()) return 0;
+    if (stream_hand_out(s->pending.front(), index, timestamp_ms, samples, data, len) != 0) return -1;
+    s->pending.erase(s->pending.begin());
+    return 1;
+}
+
+static int stream_flush_frame(flo_stream *s, StreamFrame &f) {   // 1 produced, 0 nothing buffered, < 0 error code negated
+    if (s->buf.empty()) return 0;
+    std::vector<std::vector<uint8_t>> frames;
+    int rc = stream_encode_chunks(s, s->buf.data(), 1, s->buf.size(), frames);
+    if (rc != FLO_OK) return -rc;
+    const size_t spc = s->buf.size() / s->ch;
+    f.index = s->frame_index;
+    f.timestamp_ms = (uint32_t)((double)s->total_samples / (double)s->sr * 1000.0);
+    f.samples = (uint32_t)spc;
+    f.data = std::move(frames[0]);
+    s->total_samples += spc;
+    s->frame_index++;
+    s->buf.clear();
+    return 1;
+}
+
+// flush (encoder.rs:88-110): the buffered remainder as one (partial) frame, returned, not queued. 1 / 0 as next_frame
+extern "C" int flo_stream_flush(flo_stream *s, uint32_t *index, uint32_t *timestamp_ms, uint32_t *samples, uint8_t **data, size_t *len) {
+    if (!s || !data || !len) return -1;
+    StreamFrame f;
+    int r = stream_flush_frame(s, f);
+    if (r != 1) return r < 0 ? -1 : 0;
+    return stream_hand_out(f, index, timestamp_ms, samples, data, len) == 0 ? 1 : -1;
+}
+
+// finalize (encoder.rs:113-185): a complete .flo file from the frames that have not been pulled
+extern "C" int flo_stream_finalize(flo_stream *s, const uint8_t *meta, size_t meta_len, uint8_t **out, size_t *out_len) {
+    if (!s || !out || !out_len || (meta_len && !meta)) return FLO_ERR_ARG;
+    {
+        StreamFrame f;
+        int r = stream_flush_frame(s, f);
+        if (r < 0) return -r;
+        if (r == 1) s->pending.push_back(std::move(f));
+    }
+    std::vector<uint8_t> toc, data;
+    auto put = [](std::vector<uint8_t> &v, uint64_t x, int bytes) {
+        for (int k = 0; k < bytes; k++) v.push_back((uint8_t)(x >> (8 * k)));
+    };
+    put(toc, s->pending.size(), 4);
+    uint64_t off = 0, total = 0;
+    for (const StreamFrame &f : s->pending) {
+        put(toc, f.index, 4);
+        put(toc, off, 8);
+        put(toc, f.data.size(), 4);
+        put(toc, f.timestamp_ms, 4);
+        off += f.data.size();
+        data.insert(data.end(), f.data.begin(), f.data.end());
+        total += f.samples;
+    }
+    std::vector<uint8_t> o = {'F', 'L', 'O', '!', 1, 2, 0, 0};
+    put(o, s->sr, 4);
+    o.push_back(s->ch);
+    o.push_back(s->bit_depth);
+    put(o, total, 8);
+    o.push_back(s->level);
+    put(o, 0, 3);
+    put(o, host_crc32(data.data(), data.size()), 4);
+    put(o, 66, 8);
+    put(o, toc.size(), 8);
+    put(o, data.size(), 8);
+    put(o, 0, 8);
+    put(o, meta_len, 8);
+    o.insert(o.end(), toc.begin(), toc.end());
+    o.insert(o.end(), data.begin(), data.end());
+    if (meta_len) o.insert(o.end(), meta, meta + meta_len);
+    uint8_t *p = (uint8_t *)malloc(o.size() ? o.size() : 1);
+    if (!p) return fail(s->ctx, FLO_ERR_NOMEM, "malloc failed");
+    memcpy(p, o.data(), o.size());
+    *out = p;
+    *out_len = o.size();
+    s->pending.clear();
+    return FLO_OK;
+}

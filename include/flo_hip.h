@@ -168,6 +168,28 @@ int flo_dist_gather_flush(flo_dist *d);
 int flo_dist_gather_result(flo_dist *d, const uint8_t **base, const uint64_t **rank_offsets, const uint64_t **rank_sizes);
 void *flo_dist_stream(flo_dist *d);   /* hipStream_t of the communication stream */
 
+/* ---- streaming encoder: StreamingEncoder of libflo/src/streaming/encoder.rs:6-257 -----------------------------
+ * Samples are pushed (interleaved f32); every complete one-second frame is encoded losslessly - all frames a push
+ * completes in ONE device batch - and queued; frames are pulled one by one, or assembled into a complete .flo file.
+ * Frame bytes are the reference's encode_frame_data / serialize_channel bytes (encoder.rs:215-257).
+ *   flo_stream_create  <- StreamingEncoder::new(sr, ch, bits).with_compression(level)      encoder.rs:33-56
+ *   flo_stream_push    <- push_samples                                                     :71-75
+ *   flo_stream_next_frame <- next_frame (1: a frame came out, data malloc'ed / flo_free; 0: none; -1: error)   :78-85
+ *   flo_stream_flush   <- flush: the buffered remainder as one partial frame, returned, not queued   :88-110
+ *   flo_stream_finalize <- finalize: header + TOC + DATA (+ META) of the frames not pulled yet       :113-185 */
+typedef struct flo_stream flo_stream;
+int flo_stream_create(flo_ctx *ctx, uint32_t sample_rate, uint8_t channels, uint8_t bit_depth, uint8_t level,
+                      flo_stream **out);
+void flo_stream_destroy(flo_stream *s);
+int flo_stream_push(flo_stream *s, const float *samples, size_t n_interleaved);
+size_t flo_stream_pending_samples(const flo_stream *s);   /* sample-frames waiting for a full second */
+size_t flo_stream_pending_frames(const flo_stream *s);
+int flo_stream_next_frame(flo_stream *s, uint32_t *index, uint32_t *timestamp_ms, uint32_t *samples, uint8_t **data,
+                          size_t *len);
+int flo_stream_flush(flo_stream *s, uint32_t *index, uint32_t *timestamp_ms, uint32_t *samples, uint8_t **data,
+                     size_t *len);
+int flo_stream_finalize(flo_stream *s, const uint8_t *meta, size_t meta_len, uint8_t **out, size_t *out_len);
+
 /* ---- measurement hooks ----------------------------------------------------------------------------- */
 /* When enabled, every launch of a named kernel on the ctx stream is bracketed by hipEvents on that stream. */
 int flo_ctx_profile_enable(flo_ctx *ctx, int on);

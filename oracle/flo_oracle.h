@@ -104,6 +104,20 @@ int flo_o_decode_lossless_i32(const uint8_t *flo, size_t len, int32_t **pcm, siz
                               uint32_t *sample_rate, uint8_t *channels);
 const char *flo_o_last_error(void);
 
+/* ---- streaming/encoder.rs: StreamingEncoder (lossless frames of one second, pushed and pulled) ---- */
+typedef struct flo_o_stream flo_o_stream;
+flo_o_stream *flo_o_stream_new(uint32_t sample_rate, uint8_t channels, uint8_t bit_depth, uint8_t level);     /* :33-56 */
+void flo_o_stream_free(flo_o_stream *s);
+int flo_o_stream_push(flo_o_stream *s, const float *samples, size_t n);                                       /* :71-75 */
+size_t flo_o_stream_pending_samples(const flo_o_stream *s);                                                   /* :59-61 */
+size_t flo_o_stream_pending_frames(const flo_o_stream *s);                                                    /* :64-66 */
+/* 1 = a frame came out (data malloc'ed: flo_o_free), 0 = none, -1 = error */
+int flo_o_stream_next_frame(flo_o_stream *s, uint32_t *index, uint32_t *timestamp_ms, uint32_t *samples,
+                            uint8_t **data, size_t *len);                                                     /* :78-85 */
+int flo_o_stream_flush(flo_o_stream *s, uint32_t *index, uint32_t *timestamp_ms, uint32_t *samples, uint8_t **data,
+                       size_t *len);                                                                          /* :88-110 */
+int flo_o_stream_finalize(flo_o_stream *s, const uint8_t *meta, size_t meta_len, uint8_t **out, size_t *out_len); /* :113-185 */
+
 /* ---- parsed view of a file (reader.rs:16-256), flattened for ctypes ---- */
 typedef struct {
     uint8_t version_major, version_minor;

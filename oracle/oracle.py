@@ -287,6 +287,70 @@ def info(flo: bytes) -> Info:
     return i
 
 
+class StreamingEncoder:
+    """oracle restatement of streaming::StreamingEncoder (libflo/src/streaming/encoder.rs)"""
+
+    def __init__(self, sample_rate, channels, bit_depth, level=5):
+        L = lib()
+        L.flo_o_stream_new.restype = C.c_void_p
+        L.flo_o_stream_new.argtypes = [C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint8]
+        L.flo_o_stream_free.argtypes = [C.c_void_p]
+        L.flo_o_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.flo_o_stream_pending_samples.argtypes = [C.c_void_p]
+        L.flo_o_stream_pending_samples.restype = C.c_size_t
+        L.flo_o_stream_pending_frames.argtypes = [C.c_void_p]
+        L.flo_o_stream_pending_frames.restype = C.c_size_t
+        u32p = C.POINTER(C.c_uint32)
+        L.flo_o_stream_next_frame.argtypes = [C.c_void_p, u32p, u32p, u32p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.flo_o_stream_flush.argtypes = L.flo_o_stream_next_frame.argtypes
+        L.flo_o_stream_finalize.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        self._L = L
+        self._h = C.c_void_p(L.flo_o_stream_new(sample_rate, channels, bit_depth, level))
+
+    def push_samples(self, samples):
+        p = _f32(samples)
+        if self._L.flo_o_stream_push(self._h, p.ctypes.data, p.size) != 0:
+            raise RuntimeError("oracle stream push failed")
+
+    def pending_samples(self):
+        return self._L.flo_o_stream_pending_samples(self._h)
+
+    def pending_frames(self):
+        return self._L.flo_o_stream_pending_frames(self._h)
+
+    def _pull(self, fn):
+        idx, ts, ns = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        data, n = C.c_void_p(), C.c_size_t()
+        r = fn(self._h, C.byref(idx), C.byref(ts), C.byref(ns), C.byref(data), C.byref(n))
+        if r < 0:
+            raise RuntimeError("oracle stream error")
+        if r == 0:
+            return None
+        b = C.string_at(data.value, n.value)
+        self._L.flo_o_free(data)
+        return dict(index=idx.value, timestamp_ms=ts.value, samples=ns.value, data=b)
+
+    def next_frame(self):
+        return self._pull(self._L.flo_o_stream_next_frame)
+
+    def flush(self):
+        return self._pull(self._L.flo_o_stream_flush)
+
+    def finalize(self, meta=b""):
+        out, n = C.c_void_p(), C.c_size_t()
+        if self._L.flo_o_stream_finalize(self._h, meta, len(meta), C.byref(out), C.byref(n)) != 0:
+            raise RuntimeError("oracle stream finalize failed")
+        b = C.string_at(out.value, n.value)
+        self._L.flo_o_free(out)
+        return b
+
+    def __del__(self):
+        try:
+            self._L.flo_o_stream_free(self._h)
+        except Exception:
+            pass
+
+
 def synth_clip(n_sample_frames, channels, seed=0xF10A0D10, clip_id=0):
     """Host instance of include/flo_synth.h — bit-identical to the device generator."""
     out = np.zeros(n_sample_frames * channels, np.float32)

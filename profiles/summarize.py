@@ -51,6 +51,8 @@ def main():
                                                     "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
                                                     "percent": float(r["Percentage"])}
     fetch, write, sq = counters(os.path.join(d, "fetch")), counters(os.path.join(d, "write")), counters(os.path.join(d, "sq"))
+    for k, v in counters(os.path.join(d, "sq2")).items():
+        sq.setdefault(k, {}).update(v)
     for k in set(fetch) | set(write) | set(sq):
         e = out["kernels"].setdefault(k, {})
         if k in fetch and "FETCH_SIZE" in fetch[k]:
