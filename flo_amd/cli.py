@@ -7,31 +7,68 @@ printed fields for the parts that sit on this repository's path -
     decode  <in.flo> <out.wav>
     info    <in.flo>
     validate <in.flo>
+    metadata <in.flo> [--json]
 Ingestion is WAV only (flo_amd/wav.py; the reference demuxes MP3/FLAC/OGG/AAC through symphonia, reflo/src/audio.rs:57-166).
-Files are written without a META chunk: the reference CLI embeds encoder/source metadata and analysis data as
-MessagePack (reflo/src/lib.rs:202-283), which is not part of this repository's path (out of scope), so the
---title / --artist / --album options and the `metadata` / `analysis` sub-commands are not offered.
+`encode` writes the META chunk the reference CLI writes for an untagged file (reflo/src/lib.rs:202-283, flo_amd/meta.py):
+length_ms, encoding_time, encoder_settings, flo_encoder_version, source_format (+ --title / --artist / --album) - the
+reference-made Examples/*.flo are reproduced including META, the encoding time aside. Tags inside the source file
+(RIFF INFO) are not carried over, and the `analysis` sub-command (waveform, fingerprint, EBU R128 of
+libflo/src/core/analysis.rs, ebu_r128.rs) is not offered: that analysis is outside this repository's path.
 The quality names map as in the reference CLI (main.rs:236-242): low 0.2, medium 0.4, high 0.6, veryhigh 0.8,
 transparent 1.0 - NOT the QualityPreset values the library API uses (lossy/mod.rs:39-47).
 """
 import argparse
 import sys
 
-from . import api
+import json
+import struct
+
+from . import api, meta
 from .wav import WavError, read_wav_bytes, write_wav_bytes
 
 QUALITY = {"low": 0.2, "medium": 0.4, "med": 0.4, "high": 0.6, "veryhigh": 0.8, "vh": 0.8, "transparent": 1.0, "trans": 1.0}
 QUALITY_NAMES = ["Low", "Medium", "High", "VeryHigh", "Transparent"]
 
 
-def encode_from_audio(audio_bytes: bytes, level=5, lossy=False, quality=0.6, bitrate=None, ctx=None) -> bytes:
-    """reflo::encode_from_audio (reflo/src/lib.rs:183-306) for WAV input, without the metadata step."""
+def _wav_source_format(audio_bytes: bytes) -> str:
+    """reflo/src/audio.rs:106-119 (bytes input carries no extension): the codec decides - 16 / 24 / 32-bit integer PCM
+    is "WAV", everything else "UNKNOWN" (float and 8-bit PCM are not in the reference's list)."""
+    pos = 12
+    while pos + 8 <= len(audio_bytes):
+        cid, size = audio_bytes[pos:pos + 4], struct.unpack_from("<I", audio_bytes, pos + 4)[0]
+        if cid == b"fmt " and size >= 16:
+            tag, bits = struct.unpack_from("<H", audio_bytes, pos + 8)[0], struct.unpack_from("<H", audio_bytes, pos + 22)[0]
+            if tag == 0xFFFE and size >= 26:
+                tag = struct.unpack_from("<H", audio_bytes, pos + 32)[0]
+            return "WAV" if tag == 1 and bits in (16, 24, 32) else "UNKNOWN"
+        pos += 8 + size + (size & 1)
+    return "UNKNOWN"
+
+
+def encode_from_audio(audio_bytes: bytes, level=5, lossy=False, quality=0.6, bitrate=None, ctx=None, title=None, artist=None,
+                      album=None, encoding_time=None) -> bytes:
+    """reflo::encode_from_audio (reflo/src/lib.rs:183-306) for WAV input."""
     samples, sr, ch = read_wav_bytes(audio_bytes)
     c = ctx or api.default_context()
-    if lossy or bitrate is not None:
-        q = api.QualityPreset.from_bitrate(bitrate, sr, ch).as_f32() if bitrate is not None else min(max(float(quality), 0.0), 1.0)
-        return api.TransformEncoder(sr, ch, q, c).encode_to_flo(samples, b"")
-    return api.Encoder(sr, ch, 16, c).with_compression(min(int(level), 9)).encode(samples, b"")
+    level = min(int(level), 9)
+    is_lossy = bool(lossy or bitrate is not None)
+    quality = min(max(float(quality), 0.0), 1.0)
+    mb = meta.cli_metadata(samples.size, sr, ch, _wav_source_format(audio_bytes), is_lossy, quality, bitrate, level,
+                           title, artist, album, encoding_time)
+    if is_lossy:
+        q = api.QualityPreset.from_bitrate(bitrate, sr, ch).as_f32() if bitrate is not None else quality
+        return api.TransformEncoder(sr, ch, q, c).encode_to_flo(samples, mb)
+    return api.Encoder(sr, ch, 16, c).with_compression(level).encode(samples, mb)
+
+
+def get_metadata(flo_bytes: bytes):
+    """reflo::get_metadata: the decoded META chunk (a dict), or None when the file has none."""
+    i = api.probe_container(flo_bytes)
+    meta_size = int.from_bytes(flo_bytes[62:70], "little")
+    start = i.data_start + i.data_size + int.from_bytes(flo_bytes[54:62], "little")
+    if meta_size == 0 or start + meta_size > len(flo_bytes):
+        return None
+    return meta.unpack(flo_bytes[start:start + meta_size])
 
 
 def decode_to_wav(flo_bytes: bytes, ctx=None) -> bytes:
@@ -66,11 +103,17 @@ def main(argv=None) -> int:
     e.add_argument("--transform", action="store_true", help="Use transform-based lossy")
     e.add_argument("--quality", default="high", help="Lossy quality level (low, medium, high, veryhigh, transparent)")
     e.add_argument("--bitrate", type=int, default=None, help="Target bitrate in kbps (alternative to quality)")
+    e.add_argument("--title", default=None, help="Title metadata")
+    e.add_argument("--artist", default=None, help="Artist metadata")
+    e.add_argument("--album", default=None, help="Album metadata")
     d = sub.add_parser("decode", help="Decode a flo file to WAV")
     d.add_argument("input")
     d.add_argument("output")
     i = sub.add_parser("info", help="Show information about a flo file")
     i.add_argument("input")
+    m = sub.add_parser("metadata", help="Display metadata from a flo file")
+    m.add_argument("input")
+    m.add_argument("--json", action="store_true", help="Output as JSON")
     v = sub.add_parser("validate", help="Validate a flo file")
     v.add_argument("input")
     a = ap.parse_args(argv)
@@ -93,10 +136,10 @@ def main(argv=None) -> int:
                         return 1
                     q = QUALITY[a.quality.lower()]
                     print(f"Encoding to flo (lossy, {a.quality} quality)...")
-                flo = encode_from_audio(audio, a.level, True, q if q is not None else 0.6, a.bitrate)
+                flo = encode_from_audio(audio, a.level, True, q if q is not None else 0.6, a.bitrate, None, a.title, a.artist, a.album)
             else:
                 print("Encoding to flo (lossless)...")
-                flo = encode_from_audio(audio, a.level)
+                flo = encode_from_audio(audio, a.level, title=a.title, artist=a.artist, album=a.album)
             open(a.output, "wb").write(flo)
             original = int(samples.size * 4)
             print("Done!")
@@ -133,6 +176,16 @@ def main(argv=None) -> int:
                 print(f"  Encoding:    Lossy ({QUALITY_NAMES[ql] if ql < len(QUALITY_NAMES) else 'Unknown'})")
             else:
                 print("  Encoding:    Lossless")
+        elif a.command == "metadata":
+            md = get_metadata(open(a.input, "rb").read())
+            if md is None:
+                print("null" if a.json else "No metadata present")
+            elif a.json:
+                print(json.dumps(md, indent=2, default=lambda b: f"<{len(b)} bytes>"))
+            else:
+                for k, v in md.items():
+                    shown = f"<{len(v)} bytes>" if isinstance(v, (bytes, list)) and len(v) > 16 else v
+                    print(f"  {k}: {shown}")
         elif a.command == "validate":
             try:
                 ok = flo_info(open(a.input, "rb").read())["crc_valid"]
@@ -140,7 +193,7 @@ def main(argv=None) -> int:
                 ok = False
             print("Valid flo file" if ok else "Invalid flo file")
             return 0 if ok else 1
-    except (OSError, WavError, api.FloError) as ex:
+    except (OSError, WavError, ValueError, api.FloError) as ex:
         print(f"Error: {ex}", file=sys.stderr)
         return 1
     return 0

@@ -116,3 +116,34 @@ def test_oracle_streaming_encoder_matches_its_own_one_shot_frames():
     assert int.from_bytes(out[14:22], "little") == 2 * sr + 1234            # total_samples
     assert O.crc32(out[70 + toc_size:70 + toc_size + data_size]) == int.from_bytes(out[26:30], "little")
     assert st.pending_frames() == 0 and st.finalize() [70:74] == b"\x00\x00\x00\x00"
+
+
+def test_meta_chunk_of_every_reference_made_file_is_reproduced():
+    # all 18 Examples/*.flo were written by the reference CLI (reflo/src/lib.rs:202-283): five MessagePack fields.
+    # flo_amd/meta.py rebuilds each of them byte for byte from (length, source format, settings, the file's own time)
+    import glob
+    import os
+    from conftest import ROOT
+    from flo_amd import meta
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "examples", "*.flo")))
+    assert len(files) == 18
+    for f in files:
+        b = open(f, "rb").read()
+        ms = int.from_bytes(b[62:70], "little")
+        chunk = b[len(b) - ms:]
+        md = meta.unpack(chunk)
+        assert list(md) == ["length_ms", "encoding_time", "encoder_settings", "flo_encoder_version", "source_format"], f
+        sr, ch = int.from_bytes(b[8:12], "little"), b[12]
+        lossy = bool(int.from_bytes(b[6:8], "little") & 1)
+        # the source length is not in the file; length_ms is: any sample count that yields it will do
+        n_sf = -(-md["length_ms"] * sr // 1000)
+        while int(n_sf / sr * 1000.0) < md["length_ms"]:
+            n_sf += 1
+        q = None
+        if lossy:
+            q = float(md["encoder_settings"].split("quality ")[1].rstrip("%")) / 100.0
+        rebuilt = meta.cli_metadata(n_sf * ch, sr, ch, md["source_format"], lossy, q if q is not None else 0.6, None, b[22],
+                                    encoding_time=md["encoding_time"])
+        assert rebuilt == chunk, (f, rebuilt, chunk)
+    assert meta.encoder_settings(True, 0.6, 192, 5) == "Lossy, target 192kbps"
+    assert meta.unpack(meta.pack_fields(dict(title="T" * 40, artist="A", album=None, length_ms=70000))) == {"title": "T" * 40, "artist": "A", "length_ms": 70000}

@@ -21,8 +21,11 @@ def test_cli_encode_decode_of_the_reference_example(tmp_path, capsys, ctx):
     assert cli.main(["encode", str(wav), str(out)]) == 0
     ref = example_bytes("audio_lossless.flo")
     got = out.read_bytes()
-    meta = int.from_bytes(ref[62:70], "little")
-    assert got[:62] == ref[:62] and got[70:] == ref[70:len(ref) - meta]
+    # the whole file, META included, is the file the reference tool wrote - the 20 characters of its encoding time aside
+    assert len(got) == len(ref)
+    t0 = ref.index(b"\xadencoding_time\xb4") + 15
+    assert got[:t0] == ref[:t0] and got[t0 + 20:] == ref[t0 + 20:]
+    assert cli.encode_from_audio(wav.read_bytes(), encoding_time="2026-03-09T20:46:05Z") == ref
     text = capsys.readouterr().out
     assert "Sample rate: 44100 Hz" in text and "Encoding to flo (lossless)..." in text
     back = tmp_path / "back.wav"
@@ -35,6 +38,7 @@ def test_cli_encode_decode_of_the_reference_example(tmp_path, capsys, ctx):
     rl, gl = example_bytes("audio_lossy.flo"), lossy.read_bytes()
     toc, data = int.from_bytes(gl[38:46], "little"), int.from_bytes(gl[46:54], "little")
     assert gl[:38] == rl[:38] and gl[70 + toc:70 + toc + data] == rl[70 + toc:70 + toc + data]
+    assert cli.get_metadata(gl)["encoder_settings"] == "Lossy, quality 60%" and len(gl) == len(rl)
     assert cli.main(["encode", str(wav), str(lossy), "--lossy", "--quality", "bogus"]) == 1
     assert cli.main(["info", str(lossy)]) == 0 and "Lossy (High)" in capsys.readouterr().out
 
@@ -50,10 +54,16 @@ def test_cli_on_16_bit_input_matches_the_oracle(tmp_path, ctx):
     pcm = s16.astype(np.float32) * np.float32(1 / 32768.0)          # the reference's S16 rule (audio.rs:247-253)
     out = tmp_path / "o.flo"
     assert cli.main(["encode", str(wav), str(out), "--level", "7"]) == 0
-    assert out.read_bytes() == O.encode_lossless(pcm, 22050, 2, 16, 7)
+    got = out.read_bytes()
+    md = cli.get_metadata(got)
+    assert md["source_format"] == "WAV" and md["encoder_settings"] == "Lossless, level 7" and md["length_ms"] == 30000 * 1000 // 22050
+    assert got[: len(got) - int.from_bytes(got[62:70], "little")] == O.encode_lossless(pcm, 22050, 2, 16, 7, meta=b"x" * int.from_bytes(got[62:70], "little"))[: -int.from_bytes(got[62:70], "little")]
     assert cli.main(["encode", str(wav), str(out), "--bitrate", "128"]) == 0
     q = flo_amd.QualityPreset.from_bitrate(128, 22050, 2).as_f32()
-    same_structure(out.read_bytes(), O.encode_lossy(pcm, 22050, 2, q))
+    got = out.read_bytes()
+    mb = got[len(got) - int.from_bytes(got[62:70], "little"):]
+    assert cli.get_metadata(got)["encoder_settings"] == "Lossy, target 128kbps"
+    same_structure(got, O.encode_lossy(pcm, 22050, 2, q, meta=mb))
     del rng
 
 
