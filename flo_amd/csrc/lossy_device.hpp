@@ -1144,14 +1144,12 @@ __device__ __forceinline__ void lds_st8x2_lanes(unsigned long long mask, uint32_
 // Returns the blob's length, or kSparseFallback.
 __device__ __forceinline__ uint32_t sparse_ballot_pack(const int lane, const uint32_t (&x)[16], const uint32_t blob,
                                                        const uint32_t tab) {
-    unsigned long long bal[16];
-#pragma unroll
-    for (int e = 0; e < 16; e++) bal[e] = __ballot(x[e] != 0u);
     uint32_t nM = 0, nS = 0, W = 0, cz = 0;   // non-zeros, run starts, wide records so far; zeros since the last non-zero
     unsigned long long prevbit = 0;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
-        const unsigned long long b = bal[e];
+        // the word's ballot is made where it is used: sixteen live register pairs would push scalars into spills
+        const unsigned long long b = __ballot(x[e] != 0u);
         if (b == 0ull) {   // uniform
             cz += 64u;
             prevbit = 0;
@@ -1172,20 +1170,24 @@ __device__ __forceinline__ uint32_t sparse_ballot_pack(const int lane, const uin
         const uint32_t v4 = __builtin_amdgcn_mbcnt_hi((uint32_t)(U >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)U, v2));
         const uint32_t H = blob + W;
         const uint32_t K = nM + nS + s0 + (H >> 1);
-        const uint32_t a = (v4 + K) << 1;     // v_add_lshl_u32; the odd byte of H goes into the store's offset field
-        {
-            const uint32_t hi = x[e] >> 8;
-            if (H & 1u) lds_st8x2_lanes<1>(b, a, x[e], hi);   // uniform branch
-            else lds_st8x2_lanes<0>(b, a, x[e], hi);
-        }
+        // byte address of the lane's value: 2 (items in front of it) + H; the odd bit of H is or-ed in on the vector
+        // side (one instruction) rather than chosen by a scalar branch over two store variants (a dozen)
+        const uint32_t a = ((v4 + K) << 1) | (H & 1u);
         // run table: slot = (runs before this word) + (starts of this word at or before the lane), slot 0 is a sentinel
+        const uint32_t sp = v4 - v2;
+        uint32_t ta = (sp << 2) + (tab + 4u * (nS + s0));
+        const uint32_t tmax = tab + 4u * (uint32_t)(kRunTabEntries - 1);
+        ta = ta < tmax ? ta : tmax;
+        const uint32_t ent = ((v2 << 16) + ((nM << 16) | (uint32_t)(64 * e))) | (uint32_t)lane;
         {
-            const uint32_t sp = v4 - v2;
-            uint32_t ta = (sp << 2) + (tab + 4u * (nS + s0));
-            const uint32_t tmax = tab + 4u * (uint32_t)(kRunTabEntries - 1);
-            ta = ta < tmax ? ta : tmax;
-            const uint32_t ent = ((v2 << 16) + ((nM << 16) | (uint32_t)(64 * e))) | (uint32_t)lane;
-            lds_st32_lanes(S, ta, ent);
+            // value bytes by the non-zero lanes, table entries by the run-start lanes: one save / restore of exec
+            const uint32_t hi = x[e] >> 8;
+            unsigned long long sv;
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b8 %3, %4\n\tds_write_b8 %3, %5 offset:1\n\t"
+                         "s_mov_b64 exec, %2\n\tds_write_b32 %6, %7\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv)
+                         : "s"(b), "s"(S), "v"(a), "v"(x[e]), "v"(hi), "v"(ta), "v"(ent)
+                         : "memory");
         }
         nM += (uint32_t)__builtin_popcountll(b);
         nS += (uint32_t)__builtin_popcountll(S);
