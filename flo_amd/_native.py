@@ -28,7 +28,15 @@ EXPORTS = [
     "flo_dist_gather_result", "flo_dist_stream",
     "flo_stream_create", "flo_stream_destroy", "flo_stream_push", "flo_stream_pending_samples", "flo_stream_pending_frames",
     "flo_stream_next_frame", "flo_stream_flush", "flo_stream_finalize",
+    "flo_analyze", "flo_analysis_metadata",
 ]
+
+
+class Analysis(C.Structure):
+    _fields_ = [("n_peaks", C.c_uint32), ("duration_ms", C.c_uint32), ("sample_rate", C.c_uint32), ("channels", C.c_uint8),
+                ("avg_loudness", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_uint8), ("hash", C.c_uint8 * 32),
+                ("frequency_peaks", C.c_uint8 * 8), ("energy_profile", C.c_uint8 * 16), ("integrated_lufs", C.c_double),
+                ("length_ms", C.c_uint64)]
 
 
 class ContainerInfo(C.Structure):
@@ -122,6 +130,8 @@ def lib():
     L.flo_stream_next_frame.argtypes = [vp, u32p, u32p, u32p, C.POINTER(vp), C.POINTER(sz)]
     L.flo_stream_flush.argtypes = L.flo_stream_next_frame.argtypes
     L.flo_stream_finalize.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp), C.POINTER(sz)]
+    L.flo_analyze.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_uint32, vp, sz, C.POINTER(Analysis)]
+    L.flo_analysis_metadata.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_uint32, C.POINTER(vp), C.POINTER(sz)]
     L.flo_decode.argtypes = [vp, C.c_char_p, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
     L.flo_decode_lossless_i32.argtypes = L.flo_decode.argtypes
     L.flo_probe_container.argtypes = [C.c_char_p, sz, C.POINTER(ContainerInfo), C.c_char_p, sz]

@@ -6,8 +6,8 @@ Same names, argument meaning and error behaviour as the reference (all paths und
   LossyEncoder / TransformEncoder(sample_rate, channels, quality).encode_to_flo(samples, metadata)
         -> libflo/src/lossy/encoder.rs:36-53,167-239 (re-export lib.rs:21-24)
   QualityPreset                      -> libflo/src/lossy/mod.rs:19-128
-  encode / encode_lossy / encode_with_bitrate (free functions, metadata passed through verbatim)
-        -> libflo/src/lib.rs:97-206  (the reference adds analysis metadata first; that is out of scope)
+  encode / encode_lossy / encode_with_bitrate (free functions: analysis metadata first, as the reference)
+        -> libflo/src/lib.rs:97-206, 219-283
 Errors surface as FloError(message), the analogue of FloResult<T> = Result<T, String> (core/types.rs:281).
 """
 import ctypes as C
@@ -157,6 +157,26 @@ class Context:
         finally:
             self._L.flo_free(out)
         return (a, sr.value, ch.value) if with_info else a
+
+    # -- analysis metadata of libflo::encode* (lib.rs:219-283) ---------------------------------------------------
+    def analyze(self, samples, sample_rate, channels, peaks_per_second=50):
+        """waveform peaks, spectral fingerprint and EBU R128 integrated loudness, computed on the device"""
+        p = _f32(samples)
+        peaks = np.zeros(p.size // max(channels, 1) + 16, np.float32)
+        a = _native.Analysis()
+        self._chk(self._L.flo_analyze(self._h, p.ctypes.data, p.size, sample_rate, channels, peaks_per_second,
+                                      peaks.ctypes.data, peaks.size, C.byref(a)))
+        return dict(peaks=peaks[: a.n_peaks].copy(), hash=bytes(a.hash), duration_ms=a.duration_ms, sample_rate=a.sample_rate,
+                    channels=a.channels, frequency_peaks=list(a.frequency_peaks), energy_profile=list(a.energy_profile),
+                    avg_loudness=a.avg_loudness, integrated_lufs=a.integrated_lufs, length_ms=a.length_ms)
+
+    def analysis_metadata(self, samples, sample_rate, channels, peaks_per_second=50) -> bytes:
+        """add_analysis_data_if_missing(&[], ...): the MessagePack META libflo::encode* build for an empty input META"""
+        p = _f32(samples)
+        out, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.flo_analysis_metadata(self._h, p.ctypes.data, p.size, sample_rate, channels, peaks_per_second,
+                                                C.byref(out), C.byref(n)))
+        return self._take(out, n)
 
     # -- stage-level entry points (parity tests) -----------------------------------------------------------
     def mdct_forward(self, frames):
@@ -441,18 +461,26 @@ def decode(data: bytes):
     return default_context().decode(data)
 
 
+def _with_analysis(samples, sample_rate, channels, metadata):
+    """lib.rs:105-111: `add_analysis_data_if_missing(&metadata.unwrap_or_default(), samples, sr, ch, 50)`"""
+    from . import meta as _meta
+    an = default_context().analysis_metadata(samples, sample_rate, channels, 50)
+    return _meta.merge_analysis(metadata or b"", an)
+
+
 def encode(samples, sample_rate, channels, bit_depth, metadata=None) -> bytes:
-    """lib.rs:97-117 (without the analysis-metadata step: metadata is passed through verbatim)"""
-    return Encoder(sample_rate, channels, bit_depth).encode(samples, metadata or b"")
+    """libflo::encode (lib.rs:97-117): analysis metadata first (waveform peaks, spectral fingerprint, EBU R128 loudness,
+    length), then the lossless encoder at level 5"""
+    return Encoder(sample_rate, channels, bit_depth).encode(samples, _with_analysis(samples, sample_rate, channels, metadata))
 
 
 def encode_lossy(samples, sample_rate, channels, _bit_depth, quality: int, metadata=None) -> bytes:
-    """lib.rs:135-166: quality level 0-4 -> 0.0/0.35/0.55/0.75/1.0"""
+    """libflo::encode_lossy (lib.rs:135-166): quality level 0-4 -> 0.0/0.35/0.55/0.75/1.0"""
     q = {0: 0.0, 1: 0.35, 2: 0.55, 3: 0.75}.get(int(quality), 1.0)
-    return TransformEncoder(sample_rate, channels, q).encode_to_flo(samples, metadata or b"")
+    return TransformEncoder(sample_rate, channels, q).encode_to_flo(samples, _with_analysis(samples, sample_rate, channels, metadata))
 
 
 def encode_with_bitrate(samples, sample_rate, channels, _bit_depth, target_bitrate_kbps, metadata=None) -> bytes:
-    """lib.rs:181-206"""
+    """libflo::encode_with_bitrate (lib.rs:181-206)"""
     q = QualityPreset.from_bitrate(target_bitrate_kbps, sample_rate, channels).as_f32()
-    return TransformEncoder(sample_rate, channels, q).encode_to_flo(samples, metadata or b"")
+    return TransformEncoder(sample_rate, channels, q).encode_to_flo(samples, _with_analysis(samples, sample_rate, channels, metadata))

@@ -14,6 +14,7 @@
 
 #include "../../include/flo_hip.h"
 #include "container.hpp"
+#include "analysis_kernels.hpp"
 #include "container_kernels.hpp"
 #include "decode_kernels.hpp"
 #include "devpool.hpp"
@@ -1832,5 +1833,303 @@ extern "C" int flo_stream_finalize(flo_stream *s, const uint8_t *meta, size_t me
     *out = p;
     *out_len = o.size();
     s->pending.clear();
+    return FLO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ analysis metadata
+// add_analysis_data_if_missing (lib.rs:219-283) for an empty input META: what libflo::encode / encode_lossy /
+// encode_with_bitrate put in front of the encoders. The per-sample work runs on the device (analysis_kernels.hip); what
+// is left here is scalar: the K-weighting coefficients (ebu_r128.rs:51-103), the gating of a few hundred block energies
+// (:268-318), the u8 scalings of sixteen band energies (analysis.rs:320-341) and the MessagePack framing
+// (rmp_serde::to_vec_named of FloMetadata, core/metadata.rs: the fields that are set, in declaration order).
+namespace {
+struct Mp {
+    std::vector<uint8_t> b;
+    void u(uint64_t v) {
+        if (v < 128) b.push_back((uint8_t)v);
+        else if (v < 256) { b.push_back(0xcc); b.push_back((uint8_t)v); }
+        else if (v < 65536) { b.push_back(0xcd); b.push_back((uint8_t)(v >> 8)); b.push_back((uint8_t)v); }
+        else if (v < 4294967296ull) { b.push_back(0xce); for (int k = 3; k >= 0; k--) b.push_back((uint8_t)(v >> (8 * k))); }
+        else { b.push_back(0xcf); for (int k = 7; k >= 0; k--) b.push_back((uint8_t)(v >> (8 * k))); }
+    }
+    void s(const char *t) {
+        const size_t n = strlen(t);
+        if (n < 32) b.push_back((uint8_t)(0xa0 | n));
+        else { b.push_back(0xd9); b.push_back((uint8_t)n); }
+        b.insert(b.end(), t, t + n);
+    }
+    void f(float x) {
+        uint32_t w;
+        memcpy(&w, &x, 4);
+        b.push_back(0xca);
+        for (int k = 3; k >= 0; k--) b.push_back((uint8_t)(w >> (8 * k)));
+    }
+    void arr(size_t n) {
+        if (n < 16) b.push_back((uint8_t)(0x90 | n));
+        else if (n < 65536) { b.push_back(0xdc); b.push_back((uint8_t)(n >> 8)); b.push_back((uint8_t)n); }
+        else { b.push_back(0xdd); for (int k = 3; k >= 0; k--) b.push_back((uint8_t)(n >> (8 * k))); }
+    }
+    void bin(const std::vector<uint8_t> &p) {
+        const size_t n = p.size();
+        if (n < 256) { b.push_back(0xc4); b.push_back((uint8_t)n); }
+        else if (n < 65536) { b.push_back(0xc5); b.push_back((uint8_t)(n >> 8)); b.push_back((uint8_t)n); }
+        else { b.push_back(0xc6); for (int k = 3; k >= 0; k--) b.push_back((uint8_t)(n >> (8 * k))); }
+        b.insert(b.end(), p.begin(), p.end());
+    }
+};
+uint8_t f32_as_u8(float v) {   // Rust `as u8`: saturating, NaN -> 0
+    if (!(v == v) || v <= 0.0f) return 0;
+    if (v >= 255.0f) return 255;
+    return (uint8_t)v;
+}
+float max_rust(float a, float b) {
+    if (a != a) return b;
+    if (b != b) return a;
+    return a > b ? a : b;
+}
+}  // namespace
+
+extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, uint8_t ch, uint32_t pps, float *peaks,
+                           size_t peaks_cap, flo_analysis *out) {
+    if (!c || !out || (n && !pcm) || !ch || !sr || !pps) return c ? fail(c, FLO_ERR_ARG, "flo_analyze: bad argument") : FLO_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    out->sample_rate = sr;
+    out->channels = ch;
+    out->integrated_lufs = -23.0;
+    out->length_ms = (uint64_t)((double)(n / ch) / (double)sr * 1000.0);
+    HIPCHK(c, hipSetDevice(c->device));
+    AnalysisArgs A{};
+    A.n = n;
+    A.sample_rate = sr;
+    A.channels = ch;
+    A.samples_per_peak = (double)sr / (double)pps;
+    if (n) {
+        const double tp = std::ceil((double)n / (A.samples_per_peak * (double)ch));
+        // peak windows that start inside the clip (analysis.rs:54-64: the loop breaks at the first one that does not)
+        unsigned np = 0;
+        const unsigned cap = tp > 0 ? (tp > 4e9 ? 4000000000u : (unsigned)tp) : 0u;
+        while (np < cap && (uint64_t)((double)np * A.samples_per_peak) * ch < n) np++;
+        A.n_peaks = np;
+    }
+    out->n_peaks = A.n_peaks;
+    if (!n) return FLO_OK;
+    if (peaks_cap < A.n_peaks) return fail(c, FLO_ERR_ARG, "flo_analyze: peak buffer too small");
+    // K-weighting (ebu_r128.rs:51-103) and block geometry (:190-192, :236-262)
+    {
+        const double rate = (double)sr;
+        const double f0 = 1681.974450955533, g_db = 3.999843853973347, q = 0.7071752369554196;
+        const double k = std::tan(M_PI * f0 / rate), vh = std::pow(10.0, g_db / 20.0), vb = std::pow(vh, 0.4996667741545416);
+        const double a0 = 1.0 + k / q + k * k;
+        A.shelf[0] = (vh + vb * k / q + k * k) / a0;
+        A.shelf[1] = 2.0 * (k * k - vh) / a0;
+        A.shelf[2] = (vh - vb * k / q + k * k) / a0;
+        A.shelf[3] = 2.0 * (k * k - 1.0) / a0;
+        A.shelf[4] = (1.0 - k / q + k * k) / a0;
+        const double f0h = 38.13547087602444, qh = 0.5003270373238773, kh = std::tan(M_PI * f0h / rate);
+        const double a0h = 1.0 + kh / qh + kh * kh;
+        A.hp[0] = 1.0;
+        A.hp[1] = -2.0;
+        A.hp[2] = 1.0;
+        A.hp[3] = 2.0 * (kh * kh - 1.0) / a0h;
+        A.hp[4] = (1.0 - kh / qh + kh * kh) / a0h;
+        A.hop = (unsigned)std::llround(rate * 0.1);
+    }
+    const uint64_t frames = n / ch;
+    std::vector<uint64_t> block_len;
+    if (A.hop) {
+        uint64_t start = 0;
+        const uint64_t block = (uint64_t)A.hop * 4;
+        while (start < frames) {
+            const uint64_t end = start + block < frames ? start + block : frames;
+            if (end <= start) break;
+            block_len.push_back(end - start);
+            if (end == frames) break;
+            start += A.hop;
+        }
+    }
+    A.n_blocks = (unsigned)block_len.size();
+    A.n_chunks = (9ull + 4ull * n + 1023ull) / 1024ull;
+    const uint64_t spc = n / ch;
+    const uint64_t pts[3] = {spc / 4, spc / 2, spc * 3 / 4};
+    for (int i = 0; i < 3; i++) {
+        A.points[i] = pts[i];
+        A.point_ok[i] = pts[i] + 256 < spc ? 1u : 0u;
+    }
+    // twiddles of the 256-point FFT: cos / sin in double, rounded to f32 (the values the oracle's FFT uses)
+    static float tw[8 * 128 * 2];
+    static bool have_tw = false;
+    if (!have_tw) {
+        for (int s = 0; s < 8; s++)
+            for (int k = 0; k < (1 << s); k++) {
+                const double ang = -2.0 * M_PI * (double)k / (double)(2 << s);
+                tw[(s * 128 + k) * 2] = (float)std::cos(ang);
+                tw[(s * 128 + k) * 2 + 1] = (float)std::sin(ang);
+            }
+        have_tw = true;
+    }
+    // device buffers: pcm | results
+    DevMem d_pcm, d_res, d_cvs;
+    HIPCHK(c, pool_alloc(&d_pcm.p, n * 4 + 64));
+    const size_t o_peaks = 0, o_sumsq = o_peaks + (((size_t)A.n_peaks * 4 + 15) & ~(size_t)15), o_blocks = o_sumsq + 16,
+                 o_tw = o_blocks + (((size_t)ch * A.n_blocks * 8 + 15) & ~(size_t)15), o_band = o_tw + sizeof tw, o_bin = o_band + 3 * 16 * 4,
+                 res_bytes = o_bin + 3 * 8 * 4;
+    HIPCHK(c, pool_alloc(&d_res.p, res_bytes + 64));
+    HIPCHK(c, pool_alloc(&d_cvs.p, (2 * A.n_chunks + 1) * 32 + 64));
+    int rc = ctx_stager(c);
+    if (rc != FLO_OK) return rc;
+    {
+        std::vector<UploadSeg> segs{{d_pcm.p, pcm, n * 4}};
+        std::string err;
+        if (stager_upload(c->stager, segs, c->stream, err) != 0) return fail(c, FLO_ERR_DEVICE, err);
+    }
+    HIPCHK(c, hipMemsetAsync(d_res.p, 0, res_bytes, c->stream));
+    HIPCHK(c, hipMemcpyAsync((char *)d_res.p + o_tw, tw, sizeof tw, hipMemcpyHostToDevice, c->stream));
+    A.pcm = d_pcm.as<float>();
+    char *rb = (char *)d_res.p;
+    A.peaks = (float *)(rb + o_peaks);
+    A.sumsq = (float *)(rb + o_sumsq);
+    A.block_sums = (double *)(rb + o_blocks);
+    A.fft_tw = (const float *)(rb + o_tw);
+    A.band_sqrt = (float *)(rb + o_band);
+    A.peak_bin = (unsigned int *)(rb + o_bin);
+    A.cvs = d_cvs.as<unsigned int>();
+    rc = timed_launch(c, "analysis", [&] { return launch_analysis(A, c->stream); });
+    if (rc != FLO_OK) {
+        hipStreamSynchronize(c->stream);
+        return rc;
+    }
+    std::vector<uint8_t> res(res_bytes);
+    uint32_t root[8];
+    HIPCHK(c, hipMemcpyAsync(res.data(), d_res.p, res_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(root, d_cvs.as<unsigned int>() + 2 * A.n_chunks * 8, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // waveform peaks: normalise by the largest (analysis.rs:103-109)
+    {
+        const float *pk = (const float *)(res.data() + o_peaks);
+        float mx = 0.f;
+        for (unsigned i = 0; i < A.n_peaks; i++) mx = max_rust(mx, pk[i]);
+        for (unsigned i = 0; i < A.n_peaks; i++) peaks[i] = mx > 0.f ? pk[i] / mx : pk[i];
+    }
+    // fingerprint (analysis.rs:236-356)
+    {
+        const double dms = (double)spc / (double)sr * 1000.0;
+        const uint32_t d = dms >= 4294967295.0 ? 4294967295u : (dms <= 0 ? 0u : (uint32_t)dms);
+        out->duration_ms = d < 1 ? 1 : d;
+        for (int i = 0; i < 8; i++)
+            for (int k = 0; k < 4; k++) out->hash[4 * i + k] = (uint8_t)(root[i] >> (8 * k));
+        const float *bs = (const float *)(res.data() + o_band);
+        const uint32_t *pb = (const uint32_t *)(res.data() + o_bin);
+        float bands[16] = {0};
+        uint8_t pk8[8] = {0};
+        for (int p = 0; p < 3; p++) {
+            if (!A.point_ok[p]) continue;
+            for (int b = 0; b < 16; b++) bands[b] += bs[p * 16 + b];
+            for (int b = 0; b < 8; b++) {
+                const uint8_t v = f32_as_u8((float)pb[p * 8 + b] / 256.0f * 255.0f);
+                if (v > pk8[b]) pk8[b] = v;
+            }
+        }
+        float mx = 0.f;
+        for (int b = 0; b < 16; b++) mx = max_rust(mx, bands[b]);
+        for (int b = 0; b < 16; b++) out->energy_profile[b] = mx > 0.f ? f32_as_u8(bands[b] / mx * 255.0f) : 0;
+        memcpy(out->frequency_peaks, pk8, 8);
+        const float sumsq = *(const float *)(res.data() + o_sumsq);
+        const float rms = sumsq / (float)n;
+        float v = -20.0f * log10f(rms + 1e-10f);
+        if (v == v) v = v < -60.0f ? -60.0f : (v > 0.0f ? 0.0f : v);
+        out->avg_loudness = f32_as_u8(v + 60.0f);
+    }
+    // integrated loudness: block energies summed over channels, then the two gates (ebu_r128.rs:236-318)
+    {
+        const double *bsum = (const double *)(res.data() + o_blocks);
+        std::vector<double> en(A.n_blocks);
+        for (unsigned k = 0; k < A.n_blocks; k++) {
+            double e = 0.0;
+            for (unsigned cc = 0; cc < ch; cc++) e += bsum[(size_t)cc * A.n_blocks + k] / (double)block_len[k];
+            en[k] = e;
+        }
+        double lufs = -23.0;
+        if (!en.empty()) {
+            const double abs_gate = std::pow(10.0, (-70.0 + 0.691) / 10.0);
+            double sum = 0.0;
+            size_t cnt = 0;
+            for (double e : en)
+                if (e >= abs_gate) {
+                    sum += e;
+                    cnt++;
+                }
+            if (cnt) {
+                const double ungated = -0.691 + 10.0 * std::log10(sum / (double)cnt);
+                const double rel_gate = std::pow(10.0, (ungated - 10.0 + 0.691) / 10.0);
+                double s2 = 0.0;
+                size_t c2 = 0;
+                for (double e : en)
+                    if (e >= abs_gate && e >= rel_gate) {
+                        s2 += e;
+                        c2++;
+                    }
+                lufs = c2 ? -0.691 + 10.0 * std::log10(s2 / (double)c2) : ungated;
+            }
+        }
+        out->integrated_lufs = lufs;
+    }
+    return FLO_OK;
+}
+
+extern "C" int flo_analysis_metadata(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, uint8_t ch, uint32_t pps,
+                                     uint8_t **out, size_t *out_len) {
+    if (!c || !out || !out_len) return FLO_ERR_ARG;
+    *out = nullptr;
+    *out_len = 0;
+    if (!ch || !sr || !pps) return fail(c, FLO_ERR_ARG, "flo_analysis_metadata: bad argument");
+    std::vector<float> peaks(n / ch + 16);
+    flo_analysis an;
+    int rc = flo_analyze(c, pcm, n, sr, ch, pps, peaks.data(), peaks.size(), &an);
+    if (rc != FLO_OK) return rc;
+    Mp m, fp;
+    m.b.push_back(0x84);
+    m.s("length_ms");
+    m.u(an.length_ms);
+    m.s("waveform_data");
+    m.b.push_back(0x83);
+    m.s("peaks_per_second");
+    m.u(pps);
+    m.s("peaks");
+    m.arr(an.n_peaks);
+    for (unsigned i = 0; i < an.n_peaks; i++) m.f(peaks[i]);
+    m.s("channels");
+    m.u(ch);
+    m.s("spectrum_fingerprint");
+    fp.b.push_back(0x87);
+    fp.s("hash");
+    fp.arr(32);
+    for (int i = 0; i < 32; i++) fp.u(n ? an.hash[i] : 0);
+    fp.s("duration_ms");
+    fp.u(n ? an.duration_ms : 0);
+    fp.s("sample_rate");
+    fp.u(sr);
+    fp.s("channels");
+    fp.u(ch);
+    fp.s("frequency_peaks");
+    fp.arr(8);
+    for (int i = 0; i < 8; i++) fp.u(an.frequency_peaks[i]);
+    fp.s("energy_profile");
+    fp.arr(16);
+    for (int i = 0; i < 16; i++) fp.u(an.energy_profile[i]);
+    fp.s("avg_loudness");
+    fp.u(an.avg_loudness);
+    m.bin(fp.b);
+    m.s("loudness_profile");
+    m.b.push_back(0x91);
+    m.b.push_back(0x82);
+    m.s("timestamp_ms");
+    m.u(0);
+    m.s("lufs");
+    m.f((float)an.integrated_lufs);
+    uint8_t *p = (uint8_t *)malloc(m.b.size());
+    if (!p) return fail(c, FLO_ERR_NOMEM, "malloc failed");
+    memcpy(p, m.b.data(), m.b.size());
+    *out = p;
+    *out_len = m.b.size();
     return FLO_OK;
 }

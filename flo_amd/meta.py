@@ -121,3 +121,91 @@ def unpack(data: bytes):
 
     v = one()
     return v
+
+
+# FloMetadata fields in declaration order (libflo/src/core/metadata.rs:328-665): the order rmp_serde::to_vec_named
+# writes the ones that are set
+FIELD_ORDER = """title subtitle content_group album original_album set_subtitle track_number track_total disc_number disc_total
+isrc artist album_artist conductor remixer original_artist composer lyricist original_lyricist encoded_by involved_people
+musician_credits genre mood bpm key language length_ms year recording_time release_time original_release_time encoding_time
+tagging_time copyright produced_notice publisher file_owner radio_station radio_station_owner album_sort artist_sort title_sort
+original_filename playlist_delay encoder_settings url_commercial url_copyright url_audio_file url_artist url_audio_source
+url_radio_station url_payment url_publisher user_urls comments lyrics synced_lyrics pictures user_text play_count popularimeter
+waveform_data spectrum_fingerprint bpm_map key_changes loudness_profile integrated_loudness_lufs loudness_range_lu
+true_peak_dbtp section_markers creator_notes collaboration_credits remix_chain animated_cover cover_variants artist_signature
+flo_encoder_version source_format custom""".split()
+
+
+def _skip(data: bytes, pos: int) -> int:
+    """end offset of the MessagePack value that starts at pos"""
+    t = data[pos]
+    if t < 0x80 or t >= 0xE0 or t in (0xC0, 0xC2, 0xC3):
+        return pos + 1
+    if 0xA0 <= t <= 0xBF:
+        return pos + 1 + (t & 31)
+    if 0x80 <= t <= 0x8F or 0x90 <= t <= 0x9F or t in (0xDC, 0xDD, 0xDE, 0xDF):
+        if t <= 0x9F:
+            n, p = t & 15, pos + 1
+        else:
+            w = 2 if t in (0xDC, 0xDE) else 4
+            n, p = int.from_bytes(data[pos + 1:pos + 1 + w], "big"), pos + 1 + w
+        for _ in range(n * (2 if (0x80 <= t <= 0x8F or t in (0xDE, 0xDF)) else 1)):
+            p = _skip(data, p)
+        return p
+    if t in (0xC4, 0xC5, 0xC6, 0xD9, 0xDA, 0xDB):
+        w = 1 << (t - (0xC4 if t <= 0xC6 else 0xD9))
+        return pos + 1 + w + int.from_bytes(data[pos + 1:pos + 1 + w], "big")
+    if t == 0xCA:
+        return pos + 5
+    if t == 0xCB:
+        return pos + 9
+    if 0xCC <= t <= 0xCF:
+        return pos + 1 + (1 << (t - 0xCC))
+    if 0xD0 <= t <= 0xD3:
+        return pos + 1 + (1 << (t - 0xD0))
+    raise ValueError(f"unsupported MessagePack type 0x{t:02x}")
+
+
+def _top_level(data: bytes) -> dict:
+    """top-level map as {key: raw bytes of the value}"""
+    t = data[0]
+    if 0x80 <= t <= 0x8F:
+        n, pos = t & 15, 1
+    elif t == 0xDE:
+        n, pos = int.from_bytes(data[1:3], "big"), 3
+    elif t == 0xDF:
+        n, pos = int.from_bytes(data[1:5], "big"), 5
+    else:
+        raise ValueError("META is not a MessagePack map")
+    out = {}
+    for _ in range(n):
+        kend = _skip(data, pos)
+        key = unpack(data[pos:kend])
+        vend = _skip(data, kend)
+        out[key] = data[kend:vend]
+        pos = vend
+    return out
+
+
+def merge_analysis(user_meta: bytes, analysis_meta: bytes) -> bytes:
+    """add_analysis_data_if_missing (lib.rs:219-283) for a caller who passes metadata of their own: the caller's fields
+    stay (values re-emitted as they came), waveform_data / spectrum_fingerprint / loudness_profile are added only where
+    missing, length_ms is always set; fields come out in FloMetadata's declaration order, unknown keys are dropped as
+    serde drops them, and undecodable input counts as empty (`unwrap_or_default`)."""
+    fields = {}
+    if user_meta:
+        try:
+            fields = {k: v for k, v in _top_level(user_meta).items() if k in FIELD_ORDER and v != b"\xc0"}
+        except (ValueError, IndexError):
+            fields = {}
+    an = _top_level(analysis_meta)
+    if "waveform_data" not in fields:
+        fields["waveform_data"] = an["waveform_data"]
+    if "spectrum_fingerprint" not in fields:
+        fields["spectrum_fingerprint"] = an["spectrum_fingerprint"]
+    if "loudness_profile" not in fields or fields["loudness_profile"] == b"\x90":
+        fields["loudness_profile"] = an["loudness_profile"]
+    fields["length_ms"] = an["length_ms"]
+    keys = [k for k in FIELD_ORDER if k in fields]
+    head = bytes([0x80 | len(keys)]) if len(keys) < 16 else b"\xde" + struct.pack(">H", len(keys))
+    return head + b"".join(_str(k) + fields[k] for k in keys)

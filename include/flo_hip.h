@@ -168,6 +168,28 @@ int flo_dist_gather_flush(flo_dist *d);
 int flo_dist_gather_result(flo_dist *d, const uint8_t **base, const uint64_t **rank_offsets, const uint64_t **rank_sizes);
 void *flo_dist_stream(flo_dist *d);   /* hipStream_t of the communication stream */
 
+/* ---- analysis metadata: what libflo::encode / encode_lossy / encode_with_bitrate add to META (lib.rs:219-283) -------
+ * flo_analyze computes, on the device, what add_analysis_data_if_missing computes from the samples: waveform peaks
+ * (core/analysis.rs:38-115), the spectral fingerprint (analysis.rs:223-357: BLAKE3 of the content, band energies and
+ * peak bins of three 256-point FFT sections, average loudness) and the EBU R128 integrated loudness
+ * (core/ebu_r128.rs:182-318). flo_analysis_metadata frames them as the MessagePack FloMetadata the reference serialises
+ * for an empty input META (fields length_ms, waveform_data, spectrum_fingerprint, loudness_profile; malloc'ed, flo_free):
+ * pass the result as `meta` to flo_encode_lossless / flo_encode_lossy to get what libflo::encode* return. */
+typedef struct flo_analysis {
+    uint32_t n_peaks;            /* waveform peaks written to `peaks` (normalised to the largest) */
+    uint32_t duration_ms, sample_rate;
+    uint8_t channels, avg_loudness, pad0, pad1;
+    uint8_t hash[32];
+    uint8_t frequency_peaks[8];
+    uint8_t energy_profile[16];
+    double integrated_lufs;
+    uint64_t length_ms;
+} flo_analysis;
+int flo_analyze(flo_ctx *ctx, const float *pcm, size_t n_interleaved, uint32_t sample_rate, uint8_t channels,
+                uint32_t peaks_per_second, float *peaks, size_t peaks_cap, flo_analysis *out);
+int flo_analysis_metadata(flo_ctx *ctx, const float *pcm, size_t n_interleaved, uint32_t sample_rate, uint8_t channels,
+                          uint32_t peaks_per_second, uint8_t **out, size_t *out_len);
+
 /* ---- streaming encoder: StreamingEncoder of libflo/src/streaming/encoder.rs:6-257 -----------------------------
  * Samples are pushed (interleaved f32); every complete one-second frame is encoded losslessly - all frames a push
  * completes in ONE device batch - and queued; frames are pulled one by one, or assembled into a complete .flo file.

@@ -104,6 +104,27 @@ int flo_o_decode_lossless_i32(const uint8_t *flo, size_t len, int32_t **pcm, siz
                               uint32_t *sample_rate, uint8_t *channels);
 const char *flo_o_last_error(void);
 
+/* ---- analysis metadata of libflo::encode* (lib.rs:219-283; core/analysis.rs, core/ebu_r128.rs) ---- */
+typedef struct {
+    uint8_t hash[32];
+    uint32_t duration_ms, sample_rate;
+    uint8_t channels;
+    uint8_t frequency_peaks[8], energy_profile[16];
+    uint8_t avg_loudness;
+} flo_o_fingerprint; /* analysis.rs:10-26 */
+void flo_o_blake3(const uint8_t *data, size_t len, uint8_t out32[32]);              /* blake3 crate, hash mode */
+size_t flo_o_waveform_peaks(const float *samples, size_t len, uint8_t channels, uint32_t sample_rate,
+                            uint32_t peaks_per_second, float *peaks, size_t cap);     /* analysis.rs:38-115 */
+void flo_o_fft256_twiddles(float *tw /* [8][128][2] */);
+void flo_o_spectral_fingerprint(const float *samples, size_t len, uint8_t channels, uint32_t sample_rate,
+                                flo_o_fingerprint *fp);                               /* analysis.rs:223-357 */
+void flo_o_kweighting_coeffs(double sample_rate, double shelf[5], double hp[5]);      /* ebu_r128.rs:51-103 */
+double flo_o_gated_lufs(const double *energies, size_t n);                            /* ebu_r128.rs:268-318 */
+double flo_o_integrated_lufs(const float *samples, size_t len, uint8_t channels, uint32_t sample_rate); /* :182-318 */
+/* add_analysis_data_if_missing(&[], samples, sr, ch, peaks_per_second): the META bytes (lib.rs:219-283) */
+int flo_o_analysis_metadata(const float *samples, size_t len, uint32_t sample_rate, uint8_t channels,
+                            uint32_t peaks_per_second, uint8_t **out, size_t *out_len);
+
 /* ---- streaming/encoder.rs: StreamingEncoder (lossless frames of one second, pushed and pulled) ---- */
 typedef struct flo_o_stream flo_o_stream;
 flo_o_stream *flo_o_stream_new(uint32_t sample_rate, uint8_t channels, uint8_t bit_depth, uint8_t level);     /* :33-56 */

@@ -287,6 +287,62 @@ def info(flo: bytes) -> Info:
     return i
 
 
+class _Fingerprint(C.Structure):
+    _fields_ = [("hash", C.c_uint8 * 32), ("duration_ms", C.c_uint32), ("sample_rate", C.c_uint32), ("channels", C.c_uint8),
+                ("frequency_peaks", C.c_uint8 * 8), ("energy_profile", C.c_uint8 * 16), ("avg_loudness", C.c_uint8)]
+
+
+def blake3(data: bytes) -> bytes:
+    L = lib()
+    L.flo_o_blake3.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+    o = C.create_string_buffer(32)
+    L.flo_o_blake3(bytes(data), len(data), o)
+    return o.raw
+
+
+def waveform_peaks(pcm, channels, sample_rate, peaks_per_second=50):
+    """core/analysis.rs:38-115 -> float32 array of normalised peaks"""
+    L = lib()
+    L.flo_o_waveform_peaks.restype = C.c_size_t
+    L.flo_o_waveform_peaks.argtypes = [C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
+    p = _f32(pcm)
+    out = np.zeros(p.size // max(channels, 1) + 16, np.float32)
+    n = L.flo_o_waveform_peaks(p.ctypes.data, p.size, channels, sample_rate, peaks_per_second, out.ctypes.data, out.size)
+    return out[:n].copy()
+
+
+def spectral_fingerprint(pcm, channels, sample_rate):
+    """core/analysis.rs:223-357 -> dict"""
+    L = lib()
+    L.flo_o_spectral_fingerprint.argtypes = [C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint32, C.POINTER(_Fingerprint)]
+    p = _f32(pcm)
+    fp = _Fingerprint()
+    L.flo_o_spectral_fingerprint(p.ctypes.data, p.size, channels, sample_rate, C.byref(fp))
+    return dict(hash=bytes(fp.hash), duration_ms=fp.duration_ms, sample_rate=fp.sample_rate, channels=fp.channels,
+                frequency_peaks=list(fp.frequency_peaks), energy_profile=list(fp.energy_profile), avg_loudness=fp.avg_loudness)
+
+
+def integrated_lufs(pcm, channels, sample_rate) -> float:
+    """core/ebu_r128.rs:182-318 (integrated loudness only)"""
+    L = lib()
+    L.flo_o_integrated_lufs.restype = C.c_double
+    L.flo_o_integrated_lufs.argtypes = [C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint32]
+    p = _f32(pcm)
+    return L.flo_o_integrated_lufs(p.ctypes.data, p.size, channels, sample_rate)
+
+
+def analysis_metadata(pcm, sample_rate, channels, peaks_per_second=50) -> bytes:
+    """add_analysis_data_if_missing(&[], ...) (lib.rs:219-283): the META bytes libflo::encode* build"""
+    L = lib()
+    L.flo_o_analysis_metadata.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint8, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    p = _f32(pcm)
+    out, n = C.c_void_p(), C.c_size_t()
+    L.flo_o_analysis_metadata(p.ctypes.data, p.size, sample_rate, channels, peaks_per_second, C.byref(out), C.byref(n))
+    b = C.string_at(out.value, n.value)
+    L.flo_o_free(out)
+    return b
+
+
 class StreamingEncoder:
     """oracle restatement of streaming::StreamingEncoder (libflo/src/streaming/encoder.rs)"""
 

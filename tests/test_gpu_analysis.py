@@ -1,0 +1,67 @@
+"""SURVEY 8f-3 on the device: the analysis metadata of libflo::encode* (lib.rs:219-283) against the oracle's
+restatement, field by field and as META bytes (sequential sums keep the reference's order on the device, so: equal)."""
+import numpy as np
+import pytest
+
+import flo_amd
+import signals
+from conftest import example_bytes
+from flo_amd import meta
+from flo_amd.wav import read_wav_bytes
+from gpu_util import ctx  # noqa: F401
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rng = np.random.default_rng(3)
+    yield "stereo 3 s", signals.music_like(44100, 3 * 44100 + 17, 2, seed=1), 44100, 2
+    yield "mono 8 kHz", signals.music_like(8000, 20000, 1, seed=2), 8000, 1
+    yield "three channels", signals.music_like(22050, 30001, 3, seed=3), 22050, 3
+    yield "six channels 96 kHz", signals.music_like(96000, 50000, 6, seed=4), 96000, 6
+    yield "silence", np.zeros(88200, np.float32), 44100, 2
+    yield "loud noise", (rng.uniform(-4, 4, 2 * 30000)).astype(np.float32), 48000, 2      # rms > 1: avg_loudness below 60
+    yield "shorter than one FFT", signals.music_like(44100, 200, 2, seed=5), 44100, 2
+    yield "one sample-frame", np.array([0.25, -0.5], np.float32), 44100, 2
+    for n in (253, 254, 255, 509, 510, 511, 1021, 1022):      # 9 + 4 n around the 1 KiB chunk boundaries of the hash
+        yield f"mono {n}", signals.music_like(16000, n, 1, seed=n), 16000, 1
+    yield "nan and inf", np.array([0.1, np.nan, -np.inf, 0.2] * 3000, np.float32), 44100, 2
+
+
+@pytest.mark.parametrize("name,pcm,sr,ch", list(_cases()), ids=[c[0] for c in _cases()])
+def test_analysis_equals_the_oracle(ctx, name, pcm, sr, ch):
+    a = ctx.analyze(pcm, sr, ch, 50)
+    fp = O.spectral_fingerprint(pcm, ch, sr)
+    assert np.array_equal(a["peaks"].view(np.uint32), O.waveform_peaks(pcm, ch, sr, 50).view(np.uint32))
+    assert a["hash"] == fp["hash"]
+    for k in ("duration_ms", "frequency_peaks", "energy_profile", "avg_loudness"):
+        assert a[k] == fp[k], k
+    lo = O.integrated_lufs(pcm, ch, sr)
+    assert a["integrated_lufs"] == lo or (np.isnan(a["integrated_lufs"]) and np.isnan(lo))
+    assert ctx.analysis_metadata(pcm, sr, ch, 50) == O.analysis_metadata(pcm, sr, ch, 50)
+
+
+def test_other_peak_rates_and_empty_input(ctx):
+    pcm = signals.music_like(44100, 50000, 2, seed=9)
+    for pps in (1, 10, 50, 200, 44100):
+        assert ctx.analysis_metadata(pcm, 44100, 2, pps) == O.analysis_metadata(pcm, 44100, 2, pps)
+    e = np.zeros(0, np.float32)
+    assert ctx.analysis_metadata(e, 44100, 2, 50) == O.analysis_metadata(e, 44100, 2, 50)
+
+
+def test_free_functions_equal_the_reference_pipeline(ctx):
+    # libflo::encode / encode_lossy / encode_with_bitrate (lib.rs:97-206): analysis metadata, then the encoder
+    pcm, sr, ch = read_wav_bytes(example_bytes("audio.wav"))
+    m = O.analysis_metadata(pcm, sr, ch, 50)
+    assert flo_amd.encode(pcm, sr, ch, 16) == O.encode_lossless(pcm, sr, ch, 16, 5, meta=m)
+    pcm = signals.music_like(44100, 40000, 2, seed=11)
+    m = O.analysis_metadata(pcm, 44100, 2, 50)
+    assert flo_amd.encode(pcm, 44100, 2, 24) == O.encode_lossless(pcm, 44100, 2, 24, 5, meta=m)
+    got = flo_amd.encode_lossy(pcm, 44100, 2, 16, 2)
+    ref = O.encode_lossy(pcm, 44100, 2, 0.55, meta=m)
+    assert got[-len(m):] == m and len(got) == len(ref)
+    user = meta.pack_fields(dict(title="Song", album="LP"))
+    got = flo_amd.encode_with_bitrate(pcm, 44100, 2, 16, 192, metadata=user)
+    md = meta.unpack(got[len(got) - int.from_bytes(got[62:70], "little"):])
+    assert list(md) == ["title", "album", "length_ms", "waveform_data", "spectrum_fingerprint", "loudness_profile"]
