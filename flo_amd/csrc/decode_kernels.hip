@@ -311,6 +311,7 @@ __global__ __launch_bounds__(64) void ll_decode_kernel(LlDecArgs A) {
     const unsigned t = SPREAD ? blockIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
     if (SPREAD && threadIdx.x != 0) return;
     if (t >= A.n_ch) return;
+    if (A.only && !A.only[t]) return;
     const LlChannelDev c = A.ch[t];
     int *out = A.scratch + c.out_off;
     const uint8_t *res = A.bytes + c.off;
@@ -405,7 +406,7 @@ int launch_lossy_decode(const LossyDecArgs &A, unsigned max_frames, hipStream_t 
 }
 int launch_ll_decode(const LlDecArgs &A, hipStream_t s) {
     if (!A.n_ch) return 0;
-    if (A.n_ch <= 8192) hipLaunchKernelGGL(ll_decode_kernel<1>, dim3(A.n_ch), dim3(64), 0, s, A);
+    if (A.n_ch <= 8192 || A.only) hipLaunchKernelGGL(ll_decode_kernel<1>, dim3(A.n_ch), dim3(64), 0, s, A);
     else hipLaunchKernelGGL(ll_decode_kernel<0>, dim3((A.n_ch + 63) / 64), dim3(64), 0, s, A);
     FLO_LAUNCH_CHECK();
     return 0;

@@ -37,6 +37,26 @@ struct LlDecArgs {
     const LlChannelDev *ch;
     unsigned int n_ch;
     int *scratch;                     // decoded integers, one run per channel wrapper
+    const int *only;                  // nullable [n_ch]: decode only the wrappers whose entry is nonzero
+};
+
+// Parallel form of the ALPC decode (lldec_kernels.hip). A Rice stream is cut into tiles of kRiceTileBits bits;
+// `tile0` is the running tile count over the wrappers (0 tiles for raw / silent wrappers and for those the host
+// already handed to the serial kernel through `serial`).
+constexpr int kRiceTileBits = 2048;
+constexpr int kRiceStates = 16;       // entry states of a tile: skip 0..k bits (k <= 14), or "inside a unary run" (k + 1)
+constexpr int kRiceMaxK = kRiceStates - 2;
+struct LlParArgs {
+    const uint8_t *bytes;
+    const LlChannelDev *ch;
+    unsigned int n_ch;
+    int *scratch;                     // zero-filled; residuals, then samples in place
+    const unsigned int *tile0;        // [n_ch + 1]
+    unsigned int *tabs;               // [tiles][kRiceStates]: exit state | codes started << 5, per entry state
+    uint2 *tile_entry;                // [tiles]: (index of the first code that starts in the tile, entry state)
+    int *serial;                      // [n_ch] nonzero: the serial kernel decodes this wrapper (set by the host for
+                                      // k > 14 or large coefficients, by the device for a 256-ones escape or a sample
+                                      // outside i32)
 };
 // Per frame: mid/side, interleave, int -> float.
 struct LlFrameDev {
@@ -58,6 +78,7 @@ struct LlFinishArgs {
 
 int launch_lossy_decode(const LossyDecArgs &A, unsigned max_frames, hipStream_t s);
 int launch_ll_decode(const LlDecArgs &A, hipStream_t s);
+int launch_ll_decode_parallel(const LlParArgs &A, unsigned max_tiles, hipStream_t s);
 int launch_ll_finish(const LlFinishArgs &A, unsigned max_samples, hipStream_t s);
 
 }  // namespace flo

@@ -1166,6 +1166,50 @@ extern "C" int flo_probe_container(const uint8_t *flo, size_t len, flo_container
     return FLO_OK;
 }
 
+// Device -> caller-owned pageable memory. A copy engine writes pageable memory at a fraction of the PCIe rate, so a
+// large result comes down in 8 MiB pieces through two pinned buffers: while the copy threads move piece i into the
+// caller's buffer, the copy engine is already filling the other pinned buffer with piece i + 1.
+static int download(flo_ctx *c, void *dst, const void *d_src, size_t bytes) {
+    constexpr size_t kPieceBytes = 8u << 20;
+    if (bytes <= kPieceBytes / 2) {
+        HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return FLO_OK;
+    }
+    int rc = ctx_stager(c);
+    if (rc != FLO_OK) return rc;
+    std::string err;
+    void *pin[2] = {stager_pinned_get(c->stager, kPieceBytes, err), stager_pinned_get(c->stager, kPieceBytes, err)};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    auto done = [&](int r) {
+        for (int i = 0; i < 2; i++) {
+            if (pin[i]) stager_pinned_put(c->stager, pin[i]);
+            if (ev[i]) hipEventDestroy(ev[i]);
+        }
+        return r;
+    };
+    if (!pin[0] || !pin[1]) return done(fail(c, FLO_ERR_NOMEM, err));
+    for (int i = 0; i < 2; i++)
+        if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return done(fail(c, FLO_ERR_DEVICE, "hipEventCreate failed"));
+    const size_t pieces = (bytes + kPieceBytes - 1) / kPieceBytes;
+    auto issue = [&](size_t i) -> hipError_t {
+        const size_t off = i * kPieceBytes, n = bytes - off < kPieceBytes ? bytes - off : kPieceBytes;
+        hipError_t e = hipMemcpyAsync(pin[i & 1], (const char *)d_src + off, n, hipMemcpyDeviceToHost, c->stream);
+        return e == hipSuccess ? hipEventRecord(ev[i & 1], c->stream) : e;
+    };
+    hipError_t e = issue(0);
+    if (e == hipSuccess && pieces > 1) e = issue(1);
+    for (size_t i = 0; i < pieces && e == hipSuccess; i++) {
+        const size_t off = i * kPieceBytes, n = bytes - off < kPieceBytes ? bytes - off : kPieceBytes;
+        e = hipEventSynchronize(ev[i & 1]);
+        if (e != hipSuccess) break;
+        stager_memcpy_many(c->stager, {{(char *)dst + off, pin[i & 1], n}});
+        if (i + 2 < pieces) e = issue(i + 2);
+    }
+    if (e != hipSuccess) return done(fail(c, FLO_ERR_DEVICE, std::string("download: ") + hipGetErrorString(e)));
+    return done(FLO_OK);
+}
+
 // libflo::decode (lib.rs:296-315): parse on the host (a few bytes per frame), decode on the device.
 static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, int32_t **pcm_i32, size_t *n_interleaved,
                        uint32_t *sample_rate, uint8_t *channels) {
@@ -1182,7 +1226,12 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
     const int nch = f.channels;
     DevMem d_bytes;
     HIPCHK(c, pool_alloc(&d_bytes.p, len + 32));
-    HIPCHK(c, hipMemcpyAsync(d_bytes.p, flo, len, hipMemcpyHostToDevice, c->stream));
+    {
+        int rc = ctx_stager(c);
+        if (rc != FLO_OK) return rc;
+        std::string uerr;
+        if (stager_upload(c->stager, {{d_bytes.p, flo, len}}, c->stream, uerr) != 0) return fail(c, FLO_ERR_DEVICE, uerr);
+    }
 
     if (f.is_transform) {
         if (pcm_i32 && !pcm) return fail(c, FLO_ERR_ARG, "integer output exists for lossless files only");
@@ -1242,9 +1291,9 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
             int herr = 0;
             if (rc == FLO_OK) {
                 e = hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-                if (e == hipSuccess && n_out) e = hipMemcpyAsync(host, d_out.p, n_out * sizeof(float), hipMemcpyDeviceToHost, c->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
                 if (e != hipSuccess) rc = fail(c, FLO_ERR_DEVICE, std::string("lossy decode: ") + hipGetErrorString(e));
+                if (rc == FLO_OK && n_out && !herr) rc = download(c, host, d_out.p, n_out * sizeof(float));
             }
             if (rc == FLO_OK && herr) rc = fail(c, FLO_ERR_FORMAT, "Failed to deserialize transform frame");
             if (rc != FLO_OK) {
@@ -1311,16 +1360,43 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
             if (e == hipSuccess) e = hipMemsetAsync(d_outi.p, 0, n_out * sizeof(int), c->stream);
         }
         if (e != hipSuccess) return bail(fail(c, FLO_ERR_NOMEM, std::string("decode buffers: ") + hipGetErrorString(e)));
-        LlDecArgs A{d_bytes.as<uint8_t>(), d_ch.as<LlChannelDev>(), (unsigned)chs.size(), d_scr.as<int>()};
+        // Rice tiles per wrapper; wrappers the parallel form does not take (rice.rs k > 14, coefficient sums that
+        // would leave the exact range of the f64 recurrence) go to the serial kernel
+        std::vector<unsigned int> tile0(chs.size() + 1, 0);
+        std::vector<int> serial(chs.size(), 0);
+        unsigned max_tiles = 0;
+        const bool force_serial = getenv("FLO_LL_DECODE_SERIAL") != nullptr;
+        for (size_t i = 0; i < chs.size(); i++) {
+            const LlChannelDev &d = chs[i];
+            const bool rice = d.len > 0 && (d.n_coeffs > 0 || d.shift_bits >= 128);
+            long long csum = 0;
+            for (unsigned q = 0; q < d.n_coeffs; q++) csum += d.coeffs[q] < 0 ? -(long long)d.coeffs[q] : (long long)d.coeffs[q];
+            if (force_serial || (rice && d.rice_k > kRiceMaxK) || csum >= (1ll << 22)) serial[i] = 1;
+            const unsigned nt = rice && !serial[i] ? (d.len + 255u) / 256u : 0u;
+            tile0[i + 1] = tile0[i] + nt;
+            if (nt > max_tiles) max_tiles = nt;
+        }
+        DevMem d_t0, d_ser, d_tabs, d_ent;
+        if ((rc = upload(c, d_t0, tile0)) || (rc = upload(c, d_ser, serial))) return bail(rc);
+        const size_t tiles = tile0.back();
+        e = pool_alloc(&d_tabs.p, tiles ? tiles * kRiceStates * sizeof(unsigned int) : 16);
+        if (e == hipSuccess) e = pool_alloc(&d_ent.p, tiles ? tiles * sizeof(uint2) : 16);
+        if (e == hipSuccess && scratch) e = hipMemsetAsync(d_scr.p, 0, scratch * sizeof(int), c->stream);
+        if (e != hipSuccess) return bail(fail(c, FLO_ERR_NOMEM, std::string("decode buffers: ") + hipGetErrorString(e)));
+        LlParArgs P{d_bytes.as<uint8_t>(), d_ch.as<LlChannelDev>(), (unsigned)chs.size(), d_scr.as<int>(),
+                    d_t0.as<unsigned int>(), d_tabs.as<unsigned int>(), d_ent.as<uint2>(), d_ser.as<int>()};
+        rc = timed_launch(c, "ll_decode_parallel", [&] { return launch_ll_decode_parallel(P, max_tiles, c->stream); });
+        if (rc != FLO_OK) return bail(rc);
+        LlDecArgs A{d_bytes.as<uint8_t>(), d_ch.as<LlChannelDev>(), (unsigned)chs.size(), d_scr.as<int>(), d_ser.as<int>()};
         rc = timed_launch(c, "ll_decode", [&] { return launch_ll_decode(A, c->stream); });
         if (rc != FLO_OK) return bail(rc);
         LlFinishArgs F{d_fr.as<LlFrameDev>(), d_ch.as<LlChannelDev>(), (unsigned)frs.size(), nch, d_scr.as<int>(),
                        d_out.as<float>(), d_outi.as<int>()};
         rc = timed_launch(c, "ll_finish", [&] { return launch_ll_finish(F, max_samples, c->stream); });
         if (rc != FLO_OK) return bail(rc);
-        if (host) e = hipMemcpyAsync(host, d_out.p, n_out * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && host_i) e = hipMemcpyAsync(host_i, d_outi.p, n_out * sizeof(int), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (host && (rc = download(c, host, d_out.p, n_out * sizeof(float))) != FLO_OK) return bail(rc);
+        if (host_i && (rc = download(c, host_i, d_outi.p, n_out * sizeof(int))) != FLO_OK) return bail(rc);
+        e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return bail(fail(c, FLO_ERR_DEVICE, std::string("lossless decode: ") + hipGetErrorString(e)));
     }
     if (pcm) *pcm = host;

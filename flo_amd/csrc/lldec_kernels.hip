@@ -1,0 +1,327 @@
+// lldec_kernels.hip — parallel decode of ALPC channel wrappers for gfx950.
+//
+// Reference behaviour replaced (files under /root/reference/libflo/src):
+//   core/rice.rs:123-159 (decode_i32) + :217-259 (BitReader), lossless/decoder.rs:92-150 (decode_channel_int),
+//   :152-184 (reconstruct_lpc_int), :186-266 (reconstruct_fixed).
+//
+// A Rice stream is a chain: code i + 1 starts where code i ends. What breaks the chain is that, for a fixed k, the
+// only thing a stretch of the stream needs to know about everything before it is *how it is entered*: in the middle
+// of a unary run, or with 0..k remainder bits still to skip. So
+//   1. rice_scan   : the stream is cut into tiles of 2048 bits; a lane walks one tile from one of the k + 2 possible
+//                    entry states (16 lanes per tile, 4 tiles per wavefront) and records where it leaves the tile and
+//                    how many codes started inside it;
+//   2. rice_chain  : one wavefront per wrapper follows those tables from tile to tile (a few hundred dependent LDS
+//                    reads) and notes, per tile, the real entry state and the index of its first code;
+//   3. rice_decode : a lane per tile walks its tile once more from the now known entry and writes the residuals;
+//   4. predict     : the LPC recurrence is the one truly serial piece (the shift rounds, so it is no linear scan).
+//                    One wavefront per wrapper runs it in transposed form: lane l of a 64-sample block accumulates the
+//                    prediction of sample l, every finished sample is broadcast with v_readlane and multiplied into
+//                    all later accumulators at once by one v_fma_f64 whose coefficient register is the tap vector
+//                    rotated to that step (64 rotations kept in VGPRs), so a sample costs floor + 2 readlane + fma.
+//                    Doubles are exact here: the host only admits wrappers with sum |coef| < 2^22, so every partial sum
+//                    is an integer multiple of 2^-shift below 2^53. The reference's i32 wrap-around cannot be followed
+//                    that way; a sample that leaves the i32 range flags the wrapper and the serial kernel redoes it
+//                    (as it does wrappers with k > 14, a 256-ones escape, or larger coefficients).
+//                    Fixed predictors of order 1..4 are `order` wrapping prefix sums (decoder.rs:186-266 read as
+//                    difference equations, warm-up included); raw and silent wrappers are copies.
+// Zero padding stands in for the reader's end-of-stream rules: ones up to the end then a (virtual) 0, remainder bits
+// past the end read as 0, and a value that starts past the end is 0 (the scratch is zero-filled).
+#include "decode_kernels.hpp"
+
+namespace flo {
+
+namespace {
+constexpr int kTileWords = kRiceTileBits / 32;   // 64
+constexpr int kScanTiles = 4;                    // tiles per wavefront in rice_scan
+constexpr int kScanStride = kTileWords + 2;      // a window read touches word w + 1
+constexpr int kDecOver = 16;                     // words past the last tile a code may reach (256 ones + k bits)
+constexpr int kChainChunk = 256;                 // tile tables staged per step of the chain walk
+
+__device__ __forceinline__ uint32_t be_word(const uint8_t *p, uint32_t len, uint32_t w) {
+    const uint32_t b = 4u * w;
+    if (b + 4u <= len) return ((uint32_t)p[b] << 24) | ((uint32_t)p[b + 1] << 16) | ((uint32_t)p[b + 2] << 8) | (uint32_t)p[b + 3];
+    uint32_t v = 0;
+    if (b < len) v |= (uint32_t)p[b] << 24;
+    if (b + 1u < len) v |= (uint32_t)p[b + 1] << 16;
+    if (b + 2u < len) v |= (uint32_t)p[b + 2] << 8;
+    return v;
+}
+// the 32 bits that start at bit `pos` of a big-endian word array
+__device__ __forceinline__ uint32_t window32(const uint32_t *w, uint32_t pos) {
+    const uint32_t i = pos >> 5, sh = pos & 31u;
+    const unsigned long long two = ((unsigned long long)w[i] << 32) | w[i + 1];
+    return (uint32_t)((two << sh) >> 32);
+}
+__device__ __forceinline__ uint32_t leading_ones(uint32_t x) { return x == 0xFFFFFFFFu ? 32u : (uint32_t)__clz((int)~x); }
+
+__device__ __forceinline__ bool is_rice(const LlChannelDev &c) {
+    const bool has_coeffs = c.n_coeffs > 0, has_res = c.len > 0;
+    return has_res && (has_coeffs || c.shift_bits >= 128);
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ 1. tile tables
+__global__ __launch_bounds__(64) void ll_rice_scan_kernel(LlParArgs A) {
+    __shared__ uint32_t words[kScanTiles * kScanStride];
+    const unsigned ch = blockIdx.x;
+    const unsigned nt = A.tile0[ch + 1] - A.tile0[ch];
+    const unsigned t0 = blockIdx.y * kScanTiles;
+    if (t0 >= nt) return;
+    const int lane = (int)threadIdx.x;
+    const LlChannelDev c = A.ch[ch];
+    const uint8_t *p = A.bytes + c.off;
+    for (int i = lane; i < kScanTiles * kScanStride; i += 64) {
+        const int tile = i / kScanStride, w = i - tile * kScanStride;
+        words[i] = be_word(p, c.len, (t0 + tile) * kTileWords + w);
+    }
+    __syncthreads();
+    const uint32_t k = c.rice_k;
+    const uint32_t tile = (uint32_t)lane >> 4, st = (uint32_t)lane & 15u;
+    if (st > k + 1u || t0 + tile >= nt) return;
+    const uint32_t *w = words + tile * kScanStride;
+    uint32_t pos = st <= k ? st : 0u, n = 0, exit_state;
+    bool inside = st == k + 1u;   // entered in the middle of a unary run: that code was counted where it started
+    for (;;) {
+        if (pos >= (uint32_t)kRiceTileBits) {
+            exit_state = pos - kRiceTileBits;
+            break;
+        }
+        if (!inside) n++;
+        inside = false;
+        bool found = false;
+        while (pos < (uint32_t)kRiceTileBits) {
+            const uint32_t ones = leading_ones(window32(w, pos));
+            pos += ones;
+            if (ones < 32u) {
+                found = true;
+                break;
+            }
+        }
+        if (!found || pos >= (uint32_t)kRiceTileBits) {   // the terminating 0 belongs to a later tile
+            exit_state = k + 1u;
+            break;
+        }
+        pos += 1u + k;
+    }
+    A.tabs[(size_t)(A.tile0[ch] + t0 + tile) * kRiceStates + st] = exit_state | (n << 5);
+}
+
+// ------------------------------------------------------------------------------------------------ 2. the chain
+__global__ __launch_bounds__(64) void ll_rice_chain_kernel(LlParArgs A) {
+    __shared__ uint32_t tab[kChainChunk * kRiceStates];
+    __shared__ uint2 ent[kChainChunk];
+    __shared__ uint32_t carry[2];
+    const unsigned ch = blockIdx.x;
+    const unsigned first = A.tile0[ch], nt = A.tile0[ch + 1] - first;
+    if (!nt) return;
+    const int lane = (int)threadIdx.x;
+    if (lane == 0) {
+        carry[0] = 0;   // entry state of the next tile
+        carry[1] = 0;   // codes started so far
+    }
+    for (unsigned base = 0; base < nt; base += kChainChunk) {
+        const unsigned m = nt - base < (unsigned)kChainChunk ? nt - base : (unsigned)kChainChunk;
+        for (unsigned i = lane; i < m * kRiceStates; i += 64) tab[i] = A.tabs[(size_t)(first + base) * kRiceStates + i];
+        __syncthreads();
+        if (lane == 0) {
+            uint32_t st = carry[0], idx = carry[1];
+            for (unsigned t = 0; t < m; t++) {
+                ent[t] = make_uint2(idx, st);
+                const uint32_t e = tab[t * kRiceStates + st];
+                st = e & 31u;
+                idx += e >> 5;
+            }
+            carry[0] = st;
+            carry[1] = idx;
+        }
+        __syncthreads();
+        for (unsigned t = lane; t < m; t += 64) A.tile_entry[first + base + t] = ent[t];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 3. residuals
+__global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
+    // 64 tiles of 64 words; one pad word per tile so that lanes at the same offset of their tiles hit 64 banks
+    __shared__ uint32_t words[64 * (kTileWords + 1) + kDecOver + 4];
+    const unsigned ch = blockIdx.x;
+    const unsigned first = A.tile0[ch], nt = A.tile0[ch + 1] - first;
+    const unsigned t0 = blockIdx.y * 64u;
+    if (t0 >= nt) return;
+    const int lane = (int)threadIdx.x;
+    const LlChannelDev c = A.ch[ch];
+    const uint8_t *p = A.bytes + c.off;
+    for (int i = lane; i < 64 * kTileWords + kDecOver; i += 64) words[i + (i >> 6)] = be_word(p, c.len, t0 * kTileWords + i);
+    __syncthreads();
+    const unsigned t = t0 + lane;
+    if (t >= nt) return;
+    const uint2 e = A.tile_entry[first + t];
+    const uint32_t k = c.rice_k, n = c.samples;
+    int *out = A.scratch + c.out_off;
+    // bit positions are relative to the wavefront's first tile; word i lives at words[i + i / 64]
+    auto win = [&](uint32_t pos) -> uint32_t {
+        const uint32_t i = pos >> 5, sh = pos & 31u;
+        const unsigned long long two = ((unsigned long long)words[i + (i >> 6)] << 32) | words[i + 1 + ((i + 1) >> 6)];
+        return (uint32_t)((two << sh) >> 32);
+    };
+    const uint32_t tile_lo = (uint32_t)lane * kRiceTileBits, tile_hi = tile_lo + kRiceTileBits;
+    const uint32_t limit = 64u * kRiceTileBits + 32u * (kDecOver - 2);   // staged bits a run may be followed through
+    uint32_t pos = tile_lo, idx = e.x;
+    if (e.y == k + 1u) {   // finish the run that was under way, then skip the remainder bits
+        bool found = false;
+        while (pos < tile_hi) {
+            const uint32_t ones = leading_ones(win(pos));
+            pos += ones;
+            if (ones < 32u) {
+                found = true;
+                break;
+            }
+        }
+        if (!found || pos >= tile_hi) return;
+        pos += 1u + k;
+    } else {
+        pos += e.y;
+    }
+    while (pos < tile_hi && idx < n) {
+        uint32_t q = 0;
+        for (;;) {
+            const uint32_t ones = leading_ones(win(pos));
+            q += ones;
+            pos += ones;
+            if (ones < 32u || q >= 256u || pos >= limit) break;
+        }
+        if (q >= 256u || pos >= limit) {   // the 256-ones escape (rice.rs:134-139): left to the serial reader
+            A.serial[ch] = 1;
+            return;
+        }
+        const uint32_t rem = k ? win(pos + 1u) >> (32u - k) : 0u;
+        const uint32_t u = (q << k) | rem;
+        out[idx++] = (int)(u >> 1) ^ -(int)(u & 1u);
+        pos += 1u + k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 4. predictors
+__device__ __forceinline__ int wave_scan_add(int v, int lane) {   // inclusive, wrapping
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane >= d) v = (int)((unsigned)v + (unsigned)o);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void ll_predict_kernel(LlParArgs A) {
+    __shared__ double cs[64];
+    const unsigned chi = blockIdx.x;
+    if (A.serial[chi]) return;
+    const int lane = (int)threadIdx.x;
+    const LlChannelDev c = A.ch[chi];
+    int *r = A.scratch + c.out_off;
+    const uint32_t n = c.samples;
+    const bool has_coeffs = c.n_coeffs > 0, has_res = c.len > 0;
+
+    if (!has_coeffs && has_res && c.shift_bits >= 128) {
+        // reconstruct_fixed: sample i < order uses order i, so with D^m the m-th difference, D^m_m = r_m and
+        // D^m_i = D^m_(i-1) + D^(m+1)_i: for m = order-1 .. 0 an inclusive wrapping prefix sum over a[m..]
+        const int order = c.shift_bits - 128;
+        if (order < 1 || order > 4) return;   // order 0, and unknown orders, copy the residuals
+        for (int m = order - 1; m >= 0; m--) {
+            int carry = 0;
+            for (uint32_t base = (uint32_t)m; base < n; base += 256u) {
+                int v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t i = base + 64u * j + lane;
+                    v[j] = i < n ? r[i] : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t i = base + 64u * j + lane;
+                    const int s = (int)((unsigned)wave_scan_add(v[j], lane) + (unsigned)carry);
+                    if (i < n) r[i] = s;
+                    carry = __builtin_amdgcn_readlane(s, 63);
+                }
+            }
+        }
+        return;
+    }
+    if (!has_coeffs) {
+        if (has_res) {   // raw PCM: complete i16 pairs, the rest stays 0
+            const uint8_t *p = A.bytes + c.off;
+            const uint32_t pairs = c.len >> 1;
+            for (uint32_t i = lane; i < n && i < pairs; i += 64) r[i] = (int)(short)((uint32_t)p[2 * i] | ((uint32_t)p[2 * i + 1] << 8));
+        }
+        return;   // silence: the scratch is zero-filled
+    }
+
+    // reconstruct_lpc_int
+    const int order = c.n_coeffs;
+    if (n <= (uint32_t)order || !has_res) return;   // no residual bytes: every sample is 0
+    const uint32_t sh = c.shift_bits & 63u;
+    cs[lane] = lane < order ? ldexp((double)c.coeffs[lane], -(int)sh) : 0.0;
+    __syncthreads();
+    double C[64];   // C[t][lane] = tap (lane - t - 1) mod 64: what sample t of a block adds to the prediction of sample `lane`
+#pragma unroll
+    for (int t = 0; t < 64; t++) C[t] = cs[(lane - t - 1) & 63];
+
+    // The first `order` samples are the residuals themselves. The loop below predicts them like any other sample
+    // (from the samples before them), so their residuals get that prediction taken off beforehand.
+    double acc;
+    {
+        long long v = (uint32_t)lane < n ? (long long)r[lane] : 0;
+        if (lane < order) {
+            long long pred = 0;
+            for (int j = 0; j < lane; j++) pred += (long long)c.coeffs[j] * (long long)r[lane - 1 - j];
+            v -= pred >> sh;
+        }
+        acc = (double)v;
+    }
+    double outv = 0.0;
+    bool bad = false;
+    const uint32_t nb = (n + 63u) >> 6;
+    for (uint32_t b = 0; b < nb; b++) {
+        const uint32_t nxt = 64u * (b + 1u) + (uint32_t)lane;
+        const double rn = nxt < n ? (double)r[nxt] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 64; t++) {
+            const double x = floor(acc);
+            const int lo = __builtin_amdgcn_readlane(__double2loint(x), t);
+            const int hi = __builtin_amdgcn_readlane(__double2hiint(x), t);
+            acc = fma(C[t], __hiloint2double(hi, lo), acc);
+            // a lane's accumulator is final after its own step and takes nothing more before step lane + 52, so the
+            // finished half of the block is collected, and re-armed with the next block's residuals, 32 lanes at a time
+            if (t == 31 && lane < 32) {
+                outv = acc;
+                acc = rn;
+            }
+            if (t == 63 && lane >= 32) {
+                outv = acc;
+                acc = rn;
+            }
+        }
+        const double s = floor(outv);
+        const uint32_t i = 64u * b + (uint32_t)lane;
+        if (i < n) {
+            if (!(fabs(s) < 2147483648.0)) bad = true;
+            r[i] = (int)s;
+        }
+    }
+    if (bad) A.serial[chi] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------ launcher
+int launch_ll_decode_parallel(const LlParArgs &A, unsigned max_tiles, hipStream_t s) {
+    if (!A.n_ch) return 0;
+    if (max_tiles) {
+        hipLaunchKernelGGL(ll_rice_scan_kernel, dim3(A.n_ch, (max_tiles + kScanTiles - 1) / kScanTiles), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(ll_rice_chain_kernel, dim3(A.n_ch), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(ll_rice_decode_kernel, dim3(A.n_ch, (max_tiles + 63) / 64), dim3(64), 0, s, A);
+    }
+    hipLaunchKernelGGL(ll_predict_kernel, dim3(A.n_ch), dim3(64), 0, s, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    return 0;
+}
+
+}  // namespace flo
