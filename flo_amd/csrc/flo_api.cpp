@@ -1360,8 +1360,9 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
             if (e == hipSuccess) e = hipMemsetAsync(d_outi.p, 0, n_out * sizeof(int), c->stream);
         }
         if (e != hipSuccess) return bail(fail(c, FLO_ERR_NOMEM, std::string("decode buffers: ") + hipGetErrorString(e)));
-        // Rice tiles per wrapper; wrappers the parallel form does not take (rice.rs k > 14, coefficient sums that
-        // would leave the exact range of the f64 recurrence) go to the serial kernel
+        // Rice tiles per wrapper; wrappers the parallel form does not take (rice.rs k > 14; coefficient sums or shifts
+        // that would leave the exact range of the f64 recurrence: it holds r * 2^shift + sum c * s, |r|, |s| < 2^31, in
+        // 53 bits) go to the serial kernel
         std::vector<unsigned int> tile0(chs.size() + 1, 0);
         std::vector<int> serial(chs.size(), 0);
         unsigned max_tiles = 0;
@@ -1371,7 +1372,7 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
             const bool rice = d.len > 0 && (d.n_coeffs > 0 || d.shift_bits >= 128);
             long long csum = 0;
             for (unsigned q = 0; q < d.n_coeffs; q++) csum += d.coeffs[q] < 0 ? -(long long)d.coeffs[q] : (long long)d.coeffs[q];
-            if (force_serial || (rice && d.rice_k > kRiceMaxK) || csum >= (1ll << 22)) serial[i] = 1;
+            if (force_serial || (rice && d.rice_k > kRiceMaxK) || csum >= (1ll << 21) || (d.n_coeffs && (d.shift_bits & 63u) > 20u)) serial[i] = 1;
             const unsigned nt = rice && !serial[i] ? (d.len + 255u) / 256u : 0u;
             tile0[i + 1] = tile0[i] + nt;
             if (nt > max_tiles) max_tiles = nt;

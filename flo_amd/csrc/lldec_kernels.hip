@@ -18,8 +18,9 @@
 //                    prediction of sample l, every finished sample is broadcast with v_readlane and multiplied into
 //                    all later accumulators at once by one v_fma_f64 whose coefficient register is the tap vector
 //                    rotated to that step (64 rotations kept in VGPRs), so a sample costs floor + 2 readlane + fma.
-//                    Doubles are exact here: the host only admits wrappers with sum |coef| < 2^22, so every partial sum
-//                    is an integer multiple of 2^-shift below 2^53. The reference's i32 wrap-around cannot be followed
+//                    Doubles are exact here: the host only admits wrappers with sum |coef| < 2^21 and shift <= 20, so
+//                    every partial sum (residual included) is a multiple of 2^-shift whose numerator stays below
+//                    2^31 * 2^20 + 2^21 * 2^31 < 2^53. The reference's i32 wrap-around cannot be followed
 //                    that way; a sample that leaves the i32 range flags the wrapper and the serial kernel redoes it
 //                    (as it does wrappers with k > 14, a 256-ones escape, or larger coefficients).
 //                    Fixed predictors of order 1..4 are `order` wrapping prefix sums (decoder.rs:186-266 read as

@@ -147,3 +147,30 @@ def parse_transform_blob(blob: bytes):
             i += 2 * nz
     assert p == len(blob)
     return nch, sfw, qs
+
+
+def build_lossless(sample_rate: int, channels: int, frames, version=(1, 2), bit_depth=16, level=5) -> bytes:
+    """Writer for hand-made lossless files (tests only). `frames` = [(frame_type, frame_samples, flags, [channel, ...])]
+    where a channel is either raw payload bytes (silence / raw frames) or a dict
+    {coeffs: [...], shift: int, k: int, residuals: bytes} for an ALPC wrapper (encoding byte 0 = Rice)."""
+    data = bytearray()
+    toc = []
+    ts = 0
+    for i, (ft, fs, fl, chans) in enumerate(frames):
+        off = len(data)
+        data += struct.pack("<BIB", ft, fs, fl)
+        for c in chans:
+            if isinstance(c, dict):
+                body = bytes([len(c["coeffs"])]) + struct.pack("<%di" % len(c["coeffs"]), *c["coeffs"])
+                body += bytes([c["shift"] & 0xFF, 0, c["k"] & 0xFF]) + bytes(c["residuals"])
+            else:
+                body = bytes(c)
+            data += struct.pack("<I", len(body)) + body
+        toc.append((i, off, len(data) - off, ts))
+        ts += fs * 1000 // max(sample_rate, 1)
+    tocb = struct.pack("<I", len(toc)) + b"".join(struct.pack("<IQII", *t) for t in toc)
+    total = sum(f[1] for f in frames)
+    head = b"FLO!" + struct.pack("<BBHIBBQB", version[0], version[1], 0, sample_rate, channels, bit_depth, total, level) + b"\0\0\0"
+    head += struct.pack("<IQQQQQ", zlib.crc32(bytes(data)) & 0xFFFFFFFF, 66, len(tocb), len(data), 0, 0)
+    assert len(head) == 70
+    return head + tocb + bytes(data)
