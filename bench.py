@@ -318,6 +318,25 @@ def main():
                                             "frac_of_i64_mad_peak": round(mads_per_sample * lsamples / d4 / mad_peak, 4),
                                             "hbm_algorithmic_GBs": round((4.0 * lsamples + lbytes) / d4 / 1e9, 1),
                                             "frac_of_hbm_peak": round((4.0 * lsamples + lbytes) / d4 / 1e9 / HBM_PEAK_GBS, 4)}}
+        # decode of the same batch from its files in HBM into device memory (flo_batch_decode): the parallel Rice
+        # stages + the transposed f64 LPC recurrence (lldec_kernels.hip); wall time includes reading the compressed
+        # files back once for their headers and the host-side parse
+        import torch
+        dst = torch.empty(lsamples, dtype=torch.float32, device=f"cuda:{local_rank}")
+        torch.cuda.synchronize()
+        bl.decode_to(dst.data_ptr(), dst.numel())
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        t5 = time.perf_counter()
+        for _ in range(3):
+            bl.decode_to(dst.data_ptr(), dst.numel())
+        d5 = (time.perf_counter() - t5) / 3
+        kms = sum(ctx.profile_query(k)[0] for k in ("ll_decode_parallel", "ll_decode", "ll_finish")) / 3
+        ctx.profile_enable(False)
+        out["lossless_96k"]["decode"] = {"value": round(lsamples / d5 / 1e6, 1), "unit": "Msamples/s", "ms": round(d5 * 1e3, 3),
+                                         "kernels_ms": round(kms, 3), "kernels_Msamples_s": round(lsamples / kms / 1e3, 1),
+                                         "hbm_algorithmic_GBs": round((8.0 * lsamples + lbytes) / (kms / 1e3) / 1e9, 1)}
+        del dst
         bl.close()
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as O

@@ -1210,6 +1210,93 @@ static int download(flo_ctx *c, void *dst, const void *d_src, size_t bytes) {
     return done(FLO_OK);
 }
 
+// The channel wrappers and frames of one or more parsed lossless files whose bytes sit in one device buffer
+// (lossless/decoder.rs:21-72 per file). Output sample-frames follow each other file after file.
+struct LlWork {
+    std::vector<LlChannelDev> chs;
+    std::vector<LlFrameDev> frs;
+    unsigned long long scratch = 0, out_sf = 0;
+    unsigned max_samples = 0;
+    void add(const ParsedFile &f, uint64_t base, int nch) {
+        for (const FrameDesc &fr : f.frames) {
+            LlFrameDev fd{};
+            fd.out_off = out_sf;
+            fd.first_channel = (unsigned)chs.size();
+            fd.n_channels = fr.n_channels;
+            fd.samples = fr.samples;
+            fd.mid_side = (nch == 2 && (fr.flags & 1)) ? 1u : 0u;
+            for (unsigned k = 0; k < fr.n_channels; k++) {
+                const ChannelDesc &cd = f.channels_desc[fr.first_channel + k];
+                LlChannelDev d{};
+                d.off = base + cd.off;
+                d.out_off = scratch;
+                d.len = cd.len;
+                d.samples = fr.samples;
+                d.n_coeffs = cd.n_coeffs;
+                d.shift_bits = cd.shift_bits;
+                d.rice_k = cd.rice_k;
+                memcpy(d.coeffs, cd.coeffs, sizeof d.coeffs);
+                if (k < 2) fd.scratch_off[k] = scratch;
+                scratch += fr.samples;
+                chs.push_back(d);
+            }
+            out_sf += fr.samples;
+            if (fr.samples > max_samples) max_samples = fr.samples;
+            frs.push_back(fd);
+        }
+    }
+};
+
+// Enqueue the decode of `w` on the ctx stream: integers per wrapper into a scratch, then mid/side, interleave and the
+// 1/32767 scale into d_out (f32, nullable) / d_out_i32 (nullable), both out_sf * nch elements. Returns when the
+// kernels have run.
+static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes, int nch, float *d_out, int *d_out_i32) {
+    const size_t n_out = (size_t)w.out_sf * (size_t)nch;
+    if (!n_out) return FLO_OK;
+    DevMem d_ch, d_fr, d_scr, d_t0, d_ser, d_tabs, d_ent;
+    int rc;
+    if ((rc = upload(c, d_ch, w.chs)) || (rc = upload(c, d_fr, w.frs))) return rc;
+    // Rice tiles per wrapper; wrappers the parallel form does not take (rice.rs k > 14; coefficient sums or shifts
+    // that would leave the exact range of the f64 recurrence: it holds r * 2^shift + sum c * s, |r|, |s| < 2^31, in
+    // 53 bits) go to the serial kernel
+    std::vector<unsigned int> tile0(w.chs.size() + 1, 0);
+    std::vector<int> serial(w.chs.size(), 0);
+    unsigned max_tiles = 0;
+    const bool force_serial = getenv("FLO_LL_DECODE_SERIAL") != nullptr;
+    for (size_t i = 0; i < w.chs.size(); i++) {
+        const LlChannelDev &d = w.chs[i];
+        const bool rice = d.len > 0 && (d.n_coeffs > 0 || d.shift_bits >= 128);
+        long long csum = 0;
+        for (unsigned q = 0; q < d.n_coeffs; q++) csum += d.coeffs[q] < 0 ? -(long long)d.coeffs[q] : (long long)d.coeffs[q];
+        if (force_serial || (rice && d.rice_k > kRiceMaxK) || csum >= (1ll << 21) || (d.n_coeffs && (d.shift_bits & 63u) > 20u)) serial[i] = 1;
+        const unsigned nt = rice && !serial[i] ? (d.len + 255u) / 256u : 0u;
+        tile0[i + 1] = tile0[i] + nt;
+        if (nt > max_tiles) max_tiles = nt;
+    }
+    if ((rc = upload(c, d_t0, tile0)) || (rc = upload(c, d_ser, serial))) return rc;
+    const size_t tiles = tile0.back();
+    hipError_t e = pool_alloc(&d_scr.p, w.scratch ? w.scratch * sizeof(int) : 16);
+    if (e == hipSuccess) e = pool_alloc(&d_tabs.p, tiles ? tiles * kRiceStates * sizeof(unsigned int) : 16);
+    if (e == hipSuccess) e = pool_alloc(&d_ent.p, tiles ? tiles * sizeof(uint2) : 16);
+    if (e == hipSuccess && w.scratch) e = hipMemsetAsync(d_scr.p, 0, w.scratch * sizeof(int), c->stream);
+    if (e == hipSuccess && d_out) e = hipMemsetAsync(d_out, 0, n_out * sizeof(float), c->stream);
+    if (e == hipSuccess && d_out_i32) e = hipMemsetAsync(d_out_i32, 0, n_out * sizeof(int), c->stream);
+    if (e != hipSuccess) return fail(c, FLO_ERR_NOMEM, std::string("decode buffers: ") + hipGetErrorString(e));
+    LlParArgs P{d_bytes, d_ch.as<LlChannelDev>(), (unsigned)w.chs.size(), d_scr.as<int>(),
+                d_t0.as<unsigned int>(), d_tabs.as<unsigned int>(), d_ent.as<uint2>(), d_ser.as<int>()};
+    rc = timed_launch(c, "ll_decode_parallel", [&] { return launch_ll_decode_parallel(P, max_tiles, c->stream); });
+    if (rc != FLO_OK) return rc;
+    LlDecArgs A{d_bytes, d_ch.as<LlChannelDev>(), (unsigned)w.chs.size(), d_scr.as<int>(), d_ser.as<int>()};
+    rc = timed_launch(c, "ll_decode", [&] { return launch_ll_decode(A, c->stream); });
+    if (rc != FLO_OK) return rc;
+    LlFinishArgs F{d_fr.as<LlFrameDev>(), d_ch.as<LlChannelDev>(), (unsigned)w.frs.size(), nch, d_scr.as<int>(), d_out, d_out_i32};
+    rc = timed_launch(c, "ll_finish", [&] { return launch_ll_finish(F, w.max_samples, c->stream); });
+    if (rc != FLO_OK) return rc;
+    // the descriptor uploads read pageable vectors that die with this frame, and the temporaries go back to the pool
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FLO_OK;
+}
+
 // libflo::decode (lib.rs:296-315): parse on the host (a few bytes per frame), decode on the device.
 static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, int32_t **pcm_i32, size_t *n_interleaved,
                        uint32_t *sample_rate, uint8_t *channels) {
@@ -1307,37 +1394,9 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
     }
 
     // lossless (lossless/decoder.rs:21-72)
-    std::vector<LlChannelDev> chs;
-    std::vector<LlFrameDev> frs;
-    unsigned long long scratch = 0, out_sf = 0;
-    unsigned max_samples = 0;
-    for (const FrameDesc &fr : f.frames) {
-        LlFrameDev fd{};
-        fd.out_off = out_sf;
-        fd.first_channel = (unsigned)chs.size();
-        fd.n_channels = fr.n_channels;
-        fd.samples = fr.samples;
-        fd.mid_side = (nch == 2 && (fr.flags & 1)) ? 1u : 0u;
-        for (unsigned k = 0; k < fr.n_channels; k++) {
-            const ChannelDesc &cd = f.channels_desc[fr.first_channel + k];
-            LlChannelDev d{};
-            d.off = cd.off;
-            d.out_off = scratch;
-            d.len = cd.len;
-            d.samples = fr.samples;
-            d.n_coeffs = cd.n_coeffs;
-            d.shift_bits = cd.shift_bits;
-            d.rice_k = cd.rice_k;
-            memcpy(d.coeffs, cd.coeffs, sizeof d.coeffs);
-            if (k < 2) fd.scratch_off[k] = scratch;
-            scratch += fr.samples;
-            chs.push_back(d);
-        }
-        out_sf += fr.samples;
-        if (fr.samples > max_samples) max_samples = fr.samples;
-        frs.push_back(fd);
-    }
-    const size_t n_out = nch ? (size_t)out_sf * (size_t)nch : 0;
+    LlWork w;
+    w.add(f, 0, nch);
+    const size_t n_out = nch ? (size_t)w.out_sf * (size_t)nch : 0;
     float *host = pcm ? (float *)malloc(n_out ? n_out * sizeof(float) : 1) : nullptr;
     int32_t *host_i = pcm_i32 ? (int32_t *)malloc(n_out ? n_out * sizeof(int32_t) : 1) : nullptr;
     auto bail = [&](int rc) {
@@ -1347,54 +1406,13 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
     };
     if ((pcm && !host) || (pcm_i32 && !host_i)) return bail(fail(c, FLO_ERR_NOMEM, "out of host memory"));
     if (n_out) {
-        DevMem d_ch, d_fr, d_scr, d_out, d_outi;
+        DevMem d_out, d_outi;
         int rc;
-        if ((rc = upload(c, d_ch, chs)) || (rc = upload(c, d_fr, frs))) return bail(rc);
-        hipError_t e = pool_alloc(&d_scr.p, scratch ? scratch * sizeof(int) : 16);
-        if (e == hipSuccess && host) {
-            e = pool_alloc(&d_out.p, n_out * sizeof(float));
-            if (e == hipSuccess) e = hipMemsetAsync(d_out.p, 0, n_out * sizeof(float), c->stream);
-        }
-        if (e == hipSuccess && host_i) {
-            e = pool_alloc(&d_outi.p, n_out * sizeof(int));
-            if (e == hipSuccess) e = hipMemsetAsync(d_outi.p, 0, n_out * sizeof(int), c->stream);
-        }
+        hipError_t e = hipSuccess;
+        if (host) e = pool_alloc(&d_out.p, n_out * sizeof(float));
+        if (e == hipSuccess && host_i) e = pool_alloc(&d_outi.p, n_out * sizeof(int));
         if (e != hipSuccess) return bail(fail(c, FLO_ERR_NOMEM, std::string("decode buffers: ") + hipGetErrorString(e)));
-        // Rice tiles per wrapper; wrappers the parallel form does not take (rice.rs k > 14; coefficient sums or shifts
-        // that would leave the exact range of the f64 recurrence: it holds r * 2^shift + sum c * s, |r|, |s| < 2^31, in
-        // 53 bits) go to the serial kernel
-        std::vector<unsigned int> tile0(chs.size() + 1, 0);
-        std::vector<int> serial(chs.size(), 0);
-        unsigned max_tiles = 0;
-        const bool force_serial = getenv("FLO_LL_DECODE_SERIAL") != nullptr;
-        for (size_t i = 0; i < chs.size(); i++) {
-            const LlChannelDev &d = chs[i];
-            const bool rice = d.len > 0 && (d.n_coeffs > 0 || d.shift_bits >= 128);
-            long long csum = 0;
-            for (unsigned q = 0; q < d.n_coeffs; q++) csum += d.coeffs[q] < 0 ? -(long long)d.coeffs[q] : (long long)d.coeffs[q];
-            if (force_serial || (rice && d.rice_k > kRiceMaxK) || csum >= (1ll << 21) || (d.n_coeffs && (d.shift_bits & 63u) > 20u)) serial[i] = 1;
-            const unsigned nt = rice && !serial[i] ? (d.len + 255u) / 256u : 0u;
-            tile0[i + 1] = tile0[i] + nt;
-            if (nt > max_tiles) max_tiles = nt;
-        }
-        DevMem d_t0, d_ser, d_tabs, d_ent;
-        if ((rc = upload(c, d_t0, tile0)) || (rc = upload(c, d_ser, serial))) return bail(rc);
-        const size_t tiles = tile0.back();
-        e = pool_alloc(&d_tabs.p, tiles ? tiles * kRiceStates * sizeof(unsigned int) : 16);
-        if (e == hipSuccess) e = pool_alloc(&d_ent.p, tiles ? tiles * sizeof(uint2) : 16);
-        if (e == hipSuccess && scratch) e = hipMemsetAsync(d_scr.p, 0, scratch * sizeof(int), c->stream);
-        if (e != hipSuccess) return bail(fail(c, FLO_ERR_NOMEM, std::string("decode buffers: ") + hipGetErrorString(e)));
-        LlParArgs P{d_bytes.as<uint8_t>(), d_ch.as<LlChannelDev>(), (unsigned)chs.size(), d_scr.as<int>(),
-                    d_t0.as<unsigned int>(), d_tabs.as<unsigned int>(), d_ent.as<uint2>(), d_ser.as<int>()};
-        rc = timed_launch(c, "ll_decode_parallel", [&] { return launch_ll_decode_parallel(P, max_tiles, c->stream); });
-        if (rc != FLO_OK) return bail(rc);
-        LlDecArgs A{d_bytes.as<uint8_t>(), d_ch.as<LlChannelDev>(), (unsigned)chs.size(), d_scr.as<int>(), d_ser.as<int>()};
-        rc = timed_launch(c, "ll_decode", [&] { return launch_ll_decode(A, c->stream); });
-        if (rc != FLO_OK) return bail(rc);
-        LlFinishArgs F{d_fr.as<LlFrameDev>(), d_ch.as<LlChannelDev>(), (unsigned)frs.size(), nch, d_scr.as<int>(),
-                       d_out.as<float>(), d_outi.as<int>()};
-        rc = timed_launch(c, "ll_finish", [&] { return launch_ll_finish(F, max_samples, c->stream); });
-        if (rc != FLO_OK) return bail(rc);
+        if ((rc = ll_decode_device(c, w, d_bytes.as<uint8_t>(), nch, d_out.as<float>(), d_outi.as<int>())) != FLO_OK) return bail(rc);
         if (host && (rc = download(c, host, d_out.p, n_out * sizeof(float))) != FLO_OK) return bail(rc);
         if (host_i && (rc = download(c, host_i, d_outi.p, n_out * sizeof(int))) != FLO_OK) return bail(rc);
         e = hipStreamSynchronize(c->stream);
@@ -1406,13 +1424,52 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
     return FLO_OK;
 }
 
-// Decode every clip of an encoded lossy batch from its device bitstreams (no host round trip of the payload).
+// Lossless batches: the finished files stay where the encoder left them in HBM. What the host needs of them are the
+// headers (frame sizes, wrapper parameters), so the files are read back once for parsing - compressed bytes, one
+// pinned transfer - and every wrapper of every clip is decoded in one set of launches.
+static int batch_decode_lossless(flo_batch *b, float *dst, size_t dst_cap, uint64_t *offsets) {
+    flo_ctx *c = b->ctx;
+    const uint8_t *base;
+    const uint64_t *offs, *sizes;
+    if (lossless_device_files(b->ll, &base, &offs, &sizes) != 0) return fail(c, FLO_ERR_STATE, "batch has no finished files");
+    uint64_t lo = ~0ull, hi = 0;
+    for (size_t i = 0; i < b->n_clips; i++) {
+        if (offs[i] < lo) lo = offs[i];
+        if (offs[i] + sizes[i] > hi) hi = offs[i] + sizes[i];
+    }
+    if (!b->n_clips || hi <= lo) return FLO_OK;
+    int rc = ctx_stager(c);
+    if (rc != FLO_OK) return rc;
+    std::string err;
+    uint8_t *host = (uint8_t *)stager_pinned_get(c->stager, hi - lo, err);
+    if (!host) return fail(c, FLO_ERR_NOMEM, err);
+    auto done = [&](int r) {
+        stager_pinned_put(c->stager, host);
+        return r;
+    };
+    if (hipMemcpyAsync(host, base + lo, hi - lo, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return done(fail(c, FLO_ERR_DEVICE, "reading the batch's files back for parsing failed"));
+    LlWork w;
+    for (size_t i = 0; i < b->n_clips; i++) {
+        ParsedFile f;
+        const char *perr = "";
+        if (parse_file(host + (offs[i] - lo), sizes[i], f, &perr) != 0) return done(fail(c, FLO_ERR_FORMAT, perr));
+        offsets[i] = w.out_sf * b->ch;
+        w.add(f, offs[i], b->ch);
+    }
+    const uint64_t total = w.out_sf * b->ch;
+    if (total > dst_cap) return done(fail(c, FLO_ERR_ARG, "destination too small for the decoded batch"));
+    return done(ll_decode_device(c, w, base, b->ch, dst, nullptr));
+}
+
+// Decode every clip of an encoded batch from its device bitstreams (no host round trip of the payload).
 extern "C" int flo_batch_decode(flo_batch *b, float *dst, size_t dst_cap, uint64_t *offsets) {
     if (!b || !offsets || (!dst && dst_cap)) return FLO_ERR_ARG;
     flo_ctx *c = b->ctx;
-    if (b->mode != FLO_MODE_LOSSY) return fail(c, FLO_ERR_ARG, "flo_batch_decode handles lossy batches");
     if (!b->synced) return fail(c, FLO_ERR_STATE, "call flo_batch_encode + flo_batch_sync first");
     HIPCHK(c, hipSetDevice(c->device));
+    if (b->mode != FLO_MODE_LOSSY) return batch_decode_lossless(b, dst, dst_cap, offsets);
     if (b->h_frame_size.size() != b->total_frames) {
         b->h_frame_size.assign(b->total_frames, 0);
         if (b->total_frames)

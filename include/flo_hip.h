@@ -138,9 +138,11 @@ int flo_batch_pack_streams(flo_batch *b, void *dst_device, size_t dst_cap, uint6
  * flo_batch_fetch / flo_encode_lossless patch the caller's value and the META size when they copy a file out.) */
 int flo_batch_device_files(flo_batch *b, const uint8_t **base, const uint64_t **offsets, const uint64_t **sizes);
 int flo_batch_pack_files(flo_batch *b, void *dst_device, size_t dst_cap, uint64_t *offsets);
-/* after sync, lossy batches: decode every clip from its device bitstream into dst (device memory, dst_cap floats).
- * Clip i's PCM — (frames_i - 1) * 1024 * channels floats, exactly what flo_decode returns for its file — starts at
- * offsets[i] floats (host array, n_clips entries). The payload never leaves HBM: full-size round-trip checks. */
+/* after sync: decode every clip from its device bitstream into dst (device memory, dst_cap floats). Clip i's PCM —
+ * exactly what flo_decode returns for its file: (frames_i - 1) * 1024 * channels floats for a lossy clip, the
+ * clip's interleaved samples for a lossless one — starts at offsets[i] floats (host array, n_clips entries). The
+ * payload never leaves HBM (a lossless batch's files are read back once, compressed, for their headers):
+ * full-size round-trip checks and the decode throughput figures. */
 int flo_batch_decode(flo_batch *b, float *dst_device, size_t dst_cap_floats, uint64_t *offsets);
 
 /* ---- multi-GPU: one process per GPU, one exchange step per batch -------------------------

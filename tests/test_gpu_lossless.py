@@ -172,3 +172,36 @@ def test_finished_files_in_hbm_equal_the_oracle_files(ctx):
         assert host[offs[i]:offs[i] + len(want)].tobytes() == want
         assert b.fetch(i, b"meta!") == O.encode_lossless(c, sr, 2, 16, 5, b"meta!")
     b.close()
+
+
+@pytest.mark.parametrize("n_clips,seconds,sr", [(1250, 10, 44100), (64, 10, 96000), (3, 1, 8000)])
+def test_full_size_batch_decodes_back_on_the_device(ctx, n_clips, seconds, sr):
+    """encode -> flo_batch_decode without the payload leaving HBM: every sample of every clip comes back as
+    f32_to_i32(x) / 32767 (audio_constants.rs:17-26), compared on the device; the first clip also against the oracle."""
+    import torch
+    import flo_amd
+    ch = 2
+    n_sf = seconds * sr + 17
+    b = flo_amd.Batch(ctx, flo_amd.MODE_LOSSLESS, [n_sf * ch] * n_clips, sr, ch, 5)
+    b.fill_synthetic(seed=0xF10A0D10, clip_id0=3)
+    b.encode()
+    b.sync()
+    out = torch.full((n_clips * n_sf * ch,), 7.0, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    offs = b.decode_to(out.data_ptr(), out.numel())
+    assert offs == [i * n_sf * ch for i in range(n_clips)]
+    dec = out.view(n_clips, n_sf * ch)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    step = 128
+    for i0 in range(0, n_clips, step):
+        k = min(step, n_clips - i0)
+        src = torch.empty(k, n_sf * ch, dtype=torch.float32, device="cuda:0")
+        for j in range(k):
+            assert hip.hipMemcpy(src[j].data_ptr(), b.clip_device_ptr(i0 + j), n_sf * ch * 4, 3) == 0
+        want = torch.trunc(torch.clamp(src * 32767.0, -32768.0, 32767.0)) * float(np.float32(1.0) / np.float32(32767.0))
+        assert torch.equal(dec[i0:i0 + k], want), i0
+    o_dec, _, _ = O.decode(b.fetch(0))
+    assert np.array_equal(dec[0].cpu().numpy(), o_dec)
+    b.close()
