@@ -38,8 +38,8 @@ struct LLFrame {              // one 1-second frame of one clip (host-planned)
     unsigned long long pcm_off;   // float offset of the frame slice from the PCM base
     unsigned int slice_len;       // floats in the slice (all channels)
     unsigned int frame_samples;   // slice_len / channels
-    unsigned long long plane_off; // int offset of this frame's planes in the scratch
-    unsigned int plane_stride;    // ints per channel plane
+    unsigned long long plane_off; // i16 offset of this frame's planes in the scratch (a multiple of 16)
+    unsigned int plane_stride;    // i16 elements per channel plane (a multiple of 16)
     unsigned int clip;
     unsigned int first_chan;      // index of this frame's first LLChan record
 };
@@ -68,7 +68,7 @@ struct LLChan {               // per (frame, channel)
 
 struct LLArgs {
     const float *pcm;
-    int *planes;
+    short *planes;                // f32_to_i32 of every sample is within i16 (audio_constants.rs:18-20 clamps): 2 B per sample
     const LLFrame *frames;
     LLFrameOut *fout;
     LLChan *chans;
@@ -217,6 +217,56 @@ __device__ bool levinson_fixed(const long long *autocorr, int order, int *coefs_
 }
 #pragma clang fp contract(fast)
 
+// ------------------------------------------------------------------------------------------------ plane access
+// The planes hold the converted samples per channel, L and R as they are even when the frame is coded mid/side
+// (encoder.rs:156-170: mid = l + r, side = l - r need 17 bits): the consumers form mid or side while loading, so the
+// planes are written once, at 2 bytes per sample. ms: 0 = the plane P itself, 1 = P + Q (mid), 2 = P - Q (side).
+__device__ __forceinline__ int plane_at(const short *__restrict__ P, const short *__restrict__ Q, int ms, unsigned int i) {
+    const int a = P[i];
+    if (ms == 0) return a;
+    const int b = Q[i];
+    return ms == 1 ? a + b : a - b;
+}
+__device__ __forceinline__ void unpack8(const uint4 v, int (&e)[8]) {
+    e[0] = (int)(short)(v.x & 0xFFFFu); e[1] = (int)v.x >> 16;
+    e[2] = (int)(short)(v.y & 0xFFFFu); e[3] = (int)v.y >> 16;
+    e[4] = (int)(short)(v.z & 0xFFFFu); e[5] = (int)v.z >> 16;
+    e[6] = (int)(short)(v.w & 0xFFFFu); e[7] = (int)v.w >> 16;
+}
+// w[0 .. KH) = the KH samples before i0 (zeros in front of the plane), w[KH .. KH + 16) = the run from i0 (zeros past n).
+// i0 is a multiple of 16 and the planes are 32-byte aligned, so away from the plane's ends a run is three or four
+// 16-byte loads per plane instead of one load per sample.
+template <int KH>
+__device__ __forceinline__ void load_run(const short *__restrict__ P, const short *__restrict__ Q, int ms, unsigned int i0,
+                                         unsigned int n, int (&w)[16 + KH]) {
+    static_assert(KH >= 1 && KH <= 16, "history of at most 16 samples");
+    if (i0 >= 16u && i0 + 16u <= n) {
+        constexpr int G0 = KH > 8 ? 0 : 1;   // first 8-sample group needed, counted from i0 - 16
+        int e[4][8];
+#pragma unroll
+        for (int g = G0; g < 4; g++) {
+            unpack8(*reinterpret_cast<const uint4 *>(P + i0 - 16 + 8 * g), e[g]);
+            if (ms) {
+                int q[8];
+                unpack8(*reinterpret_cast<const uint4 *>(Q + i0 - 16 + 8 * g), q);
+#pragma unroll
+                for (int j = 0; j < 8; j++) e[g][j] = ms == 1 ? e[g][j] + q[j] : e[g][j] - q[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16 + KH; j++) {
+            const int src = 16 - KH + j;   // position counted from i0 - 16
+            w[j] = e[src >> 3][src & 7];
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 16 + KH; j++) {
+        const long long idx = (long long)i0 - KH + j;
+        w[j] = (idx >= 0 && idx < (long long)n) ? plane_at(P, Q, ms, (unsigned int)idx) : 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ ll_prepare
 __global__ __launch_bounds__(kLLThreads) void ll_prepare_kernel(LLArgs A) {
     __shared__ long long red[kLLThreads / 64];
@@ -226,14 +276,37 @@ __global__ __launch_bounds__(kLLThreads) void ll_prepare_kernel(LLArgs A) {
     const LLFrame fr = A.frames[f];
     const float *src = A.pcm + fr.pcm_off;
     const int ch = A.nch;
-    int *planes = A.planes + fr.plane_off;
-    // pass 1: silence test over every float of the slice (encoder.rs:70) + convert + de-interleave
+    short *planes = A.planes + fr.plane_off;
+    // One pass over the slice: silence test over every float (encoder.rs:70), f32 -> i32 -> i16 planes, and for stereo
+    // the i64 energies of L, R and L - R over the common length (encoder.rs:131-153) from the same registers.
     int loud = 0;
-    for (unsigned int i = threadIdx.x; i < fr.slice_len; i += kLLThreads) {
-        float s = src[i];
-        if (!(fabsf(s) < 1e-7f)) loud = 1;
-        unsigned int c = i % (unsigned int)ch, p = i / (unsigned int)ch;
-        planes[(size_t)c * fr.plane_stride + p] = f32_to_i32(s);
+    long long vl = 0, vr = 0, vs = 0;
+    if (ch == 2) {
+        const unsigned int n1 = fr.slice_len / 2;   // complete sample-frames; an odd slice ends with a lone L sample
+        short *L = planes, *R = planes + fr.plane_stride;
+        for (unsigned int p = threadIdx.x; p < n1; p += kLLThreads) {
+            const float a = src[2 * p], b = src[2 * p + 1];
+            if (!(fabsf(a) < 1e-7f) || !(fabsf(b) < 1e-7f)) loud = 1;
+            const int l = f32_to_i32(a), r = f32_to_i32(b);
+            L[p] = (short)l;
+            R[p] = (short)r;
+            vl += (long long)(l * l);
+            vr += (long long)(r * r);
+            const int d = l - r;
+            vs += (long long)d * d;
+        }
+        if ((fr.slice_len & 1u) && threadIdx.x == 0) {
+            const float a = src[fr.slice_len - 1];
+            if (!(fabsf(a) < 1e-7f)) loud = 1;
+            L[n1] = (short)f32_to_i32(a);
+        }
+    } else {
+        for (unsigned int i = threadIdx.x; i < fr.slice_len; i += kLLThreads) {
+            const float v = src[i];
+            if (!(fabsf(v) < 1e-7f)) loud = 1;
+            const unsigned int c = i % (unsigned int)ch, p = i / (unsigned int)ch;
+            planes[(size_t)c * fr.plane_stride + p] = (short)f32_to_i32(v);
+        }
     }
     if (threadIdx.x == 0) s_flag = 0;
     __syncthreads();
@@ -241,31 +314,11 @@ __global__ __launch_bounds__(kLLThreads) void ll_prepare_kernel(LLArgs A) {
     __syncthreads();
     const int silent = !s_flag;
     int use_ms = 0;
-    if (!silent && ch == 2) {
-        // encoder.rs:131-153: i64 energies of L, R and L-R over the common length
-        const unsigned int n0 = (fr.slice_len + 1) / 2, n1 = fr.slice_len / 2;
-        const unsigned int m = n0 < n1 ? n0 : n1;
-        const int *L = planes, *R = planes + fr.plane_stride;
-        long long vl = 0, vr = 0, vs = 0;
-        for (unsigned int i = threadIdx.x; i < m; i += kLLThreads) {
-            long long l = L[i], r = R[i];
-            vl += l * l;
-            vr += r * r;
-            long long d = (int)(l - r);
-            vs += d * d;
-        }
+    if (ch == 2) {   // uniform: every thread takes part in the sums
         vl = block_sum(vl, red);
         vr = block_sum(vr, red);
         vs = block_sum(vs, red);
-        use_ms = vs < (vl + vr) / 2;
-        if (use_ms) {
-            int *Lw = planes, *Rw = planes + fr.plane_stride;
-            for (unsigned int i = threadIdx.x; i < m; i += kLLThreads) {
-                int l = Lw[i], r = Rw[i];
-                Lw[i] = l + r;  // mid  (encoder.rs:156-170)
-                Rw[i] = l - r;  // side
-            }
-        }
+        use_ms = !silent && vs < (vl + vr) / 2;
     }
     if (threadIdx.x == 0) {
         A.fout[f].silent = silent;
@@ -317,7 +370,9 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
         return;
     }
     const unsigned int n = out->n;
-    const int *s = A.planes + fr.plane_off + (size_t)c * fr.plane_stride;
+    const int ms = A.fout[f].use_ms ? (c == 0 ? 1 : 2) : 0;
+    const short *P = A.planes + fr.plane_off + (ms ? 0 : (size_t)c * fr.plane_stride);
+    const short *Q = P + fr.plane_stride;
     constexpr int max_order = MAXO;
     constexpr int kLpcOrders = MAXO > 4 ? MAXO - 4 : 0;   // LPC candidates: orders 5..MAXO
     constexpr int fixed_max = max_order < 4 ? max_order : 4;
@@ -331,13 +386,8 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
 #endif
     constexpr int kRun = FLO_LL_RUN, kHist = MAXO > 4 ? MAXO : 4, kWin = kRun + kHist;
     const unsigned int tile = kLLThreads * kRun;
-    auto load_window = [&](unsigned int i0, int (&w)[kWin]) {
-#pragma unroll
-        for (int j = 0; j < kWin; j++) {
-            const long long idx = (long long)i0 - kHist + j;
-            w[j] = (idx >= 0 && idx < (long long)n) ? s[idx] : 0;
-        }
-    };
+    static_assert(kRun == 16, "load_run deals 16-sample runs");
+    auto load_window = [&](unsigned int i0, int (&w)[kWin]) { load_run<kHist>(P, Q, ms, i0, n, w); };
     // All fixed-predictor residuals of a run by repeated differencing: order o is the difference of two order o - 1
     // residuals (in wrapping 32-bit arithmetic this equals the binomial form truncated from i64), 4.4 subtractions
     // per sample for the five orders together. D[o][j] is the order-o residual of sample i0 + j computed with zeros in
@@ -765,11 +815,13 @@ __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
     unsigned long long res_pos = pos + 4;
     if (ch.alpc_layout) res_pos += 1 + 4 * (ch.kind == 2 ? ch.order : 0) + 1 + 1 + (ch.kind == 0 ? 0 : 1);
     const unsigned int n = ch.n;
-    const int *s = A.planes + fr.plane_off + (size_t)c * fr.plane_stride;
+    const int ms = fo.use_ms ? (c == 0 ? 1 : 2) : 0;
+    const short *P = A.planes + fr.plane_off + (ms ? 0 : (size_t)c * fr.plane_stride);
+    const short *Q = P + fr.plane_stride;
     if (ch.kind == 0) {
         // raw PCM: (s as i16).to_le_bytes() (encoder.rs:220-226), wrapping truncation
         for (unsigned int i = threadIdx.x; i < n; i += kLLThreads)
-            or_bytes(out, res_pos + 2ull * i, (unsigned int)(unsigned short)(short)s[i], 2);
+            or_bytes(out, res_pos + 2ull * i, (unsigned int)(unsigned short)(short)plane_at(P, Q, ms, i), 2);
         return;
     }
     // Rice (rice.rs:94-114), in tiles of 256 threads x 16 consecutive samples: a tile spans 16 KiB of the plane that the
@@ -788,11 +840,7 @@ __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
         if (i0 < i1) {
             // the thread's 16 samples and the 12 before them, once; every predictor tap is then a register operand
             int w[kPer + kMaxOrder];
-#pragma unroll
-            for (int j = 0; j < (int)kPer + kMaxOrder; j++) {
-                const long long idx = (long long)i0 - kMaxOrder + j;
-                w[j] = (idx >= 0 && idx < (long long)n) ? s[idx] : 0;
-            }
+            load_run<kMaxOrder>(P, Q, ms, i0, n, w);
             // residuals of the run: one straight-line instantiation per predictor (the choice is uniform over the
             // workgroup), so every tap and every window index is a compile-time constant
             if (ch.kind == 1) {
@@ -926,7 +974,7 @@ struct LosslessPlan {
     LLFrame *d_frames = nullptr;
     LLFrameOut *d_fout = nullptr;
     LLChan *d_chans = nullptr;
-    int *d_planes = nullptr;
+    short *d_planes = nullptr;
     uint32_t *d_cff = nullptr;
     uint64_t *d_coo = nullptr, *d_clip_bytes = nullptr, *d_cf0 = nullptr;
     uint32_t *d_fsize = nullptr, *d_fsamp = nullptr, *d_cfn = nullptr, *d_crc = nullptr, *d_part = nullptr;
@@ -978,7 +1026,7 @@ LosslessPlan *lossless_plan_create(const std::vector<uint64_t> &n_il, const std:
             fr.pcm_off = clip_off[i] + start;
             fr.slice_len = (uint32_t)(end - start);
             fr.frame_samples = (uint32_t)((end - start) / ch);
-            fr.plane_stride = (uint32_t)((end - start + ch - 1) / ch);
+            fr.plane_stride = (uint32_t)(((end - start + ch - 1) / ch + 15) & ~15ull);
             fr.plane_off = planes;
             fr.clip = (uint32_t)i;
             fr.first_chan = (uint32_t)(p->frames.size() * ch);
@@ -1009,7 +1057,7 @@ LosslessPlan *lossless_plan_create(const std::vector<uint64_t> &n_il, const std:
     LCHK(pool_alloc(&p->d_frames, (nf + 1) * sizeof(LLFrame)));
     LCHK(pool_alloc(&p->d_fout, (nf + 1) * sizeof(LLFrameOut)));
     LCHK(pool_alloc(&p->d_chans, (p->n_chans + 1) * sizeof(LLChan)));
-    LCHK(pool_alloc(&p->d_planes, (planes + 4) * sizeof(int)));
+    LCHK(pool_alloc(&p->d_planes, (planes + 16) * sizeof(short)));
     LCHK(pool_alloc(&p->d_cff, (p->n_clips + 1) * 4));
     LCHK(pool_alloc(&p->d_coo, (p->n_clips + 1) * 8));
     LCHK(pool_alloc(&p->d_clip_bytes, (p->n_clips + 1) * 8));
