@@ -121,7 +121,7 @@ def main():
     batch.fill_synthetic(seed=0xF10A0D10, clip_id0=rank * args.clips_per_gpu)
     samples_per_step_rank = n_il * args.clips_per_gpu
 
-    gather = None
+    gather, gather_error = None, None
     if world > 1:
         # the exchange step lives behind the C ABI (flo_dist_*: RCCL directly, own stream, double-buffered); torch's
         # process group only carries the 128-byte rendezvous token from rank 0 to the others
@@ -130,7 +130,17 @@ def main():
         if rank == 0:
             tok.copy_(torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8))
         dist.broadcast(tok, src=0)
-        gather = NativeGather(ctx, bytes(tok.cpu().numpy().tobytes()), rank, world, 0)
+        try:
+            gather = NativeGather(ctx, bytes(tok.cpu().numpy().tobytes()), rank, world, 0)
+        except Exception as e:   # noqa: BLE001 - reported in the JSON line, never silent
+            gather_error = f"rank {rank}: {e}"
+        # every rank must take the same branch: if the communicator failed anywhere, nobody gathers (and the line says so)
+        ok = torch.tensor([1 if gather is not None else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            gather = None
+            gather_error = gather_error or "the RCCL communicator of flo_dist_create failed on another rank"
+            print(f"[bench] exchange step disabled: {gather_error}", file=sys.stderr)
 
     def step():
         batch.encode(args.path)
@@ -194,6 +204,10 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "realtime_factor": round(value * 1e6 / (sr * ch), 1),
+        "exchange": ("none (one rank)" if world == 1 else
+                     ("every rank's finished files gathered to rank 0 each step: flo_dist_* (ncclAllGather of sizes + "
+                      "grouped ncclSend/ncclRecv on its own stream, overlapping the next encode), inside the timed region"
+                      if gather is not None else f"DISABLED, files stayed on their ranks: {gather_error}")),
         "config": {
             "workload": f"{args.clips_per_gpu} x {args.clip_seconds:g} s 44.1 kHz stereo clips per GPU, lossy quality=high "
                         f"(0.55)" + (": BASELINE configs[3], the 10 000-clip corpus, whole on each GPU (35 GB of PCM resident in "
