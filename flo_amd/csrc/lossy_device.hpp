@@ -727,6 +727,54 @@ __device__ __forceinline__ float spread_threshold(const int lane, float energy, 
     return m + (-6.0f);
 }
 
+// The same for both channels of a stereo frame in ONE pass: channel 0's bands on lanes 0..24, channel 1's on lanes
+// 32..56 (band = lane & 31). Every lane goes through exactly the operations of spread_threshold; what differs is the
+// bookkeeping between the halves: the row-0 / row-2 lanes take bands 16..24 from lane 16 / 48, and the shifted copy of
+// channel 0's band 24 is kept from reaching channel 1's band 0 (it arrives at lane 32 after exactly eight shifts).
+__device__ __forceinline__ float spread_threshold_2(const int lane, float energy, float rcount, const LossyDevTables &T) {
+    const float4 sd0 = T.pack[45 * 64], sd1 = T.pack[45 * 64 + 1];
+    const int b = lane & 31;
+    const bool is_band = b < 25;
+    float band_db = -100.0f;
+    if (is_band && rcount > 0.f && energy > 1e-10f) band_db = 3.01029995663981195f * __builtin_amdgcn_logf(energy * rcount);
+    if (!is_band) band_db = -__builtin_inff();
+    const float ninf = -__builtin_inff();
+    float sm = band_db;
+    sm = max_raw(sm, dpp_f<0x101>(ninf, sm));
+    sm = max_raw(sm, dpp_f<0x102>(ninf, sm));
+    sm = max_raw(sm, dpp_f<0x104>(ninf, sm));
+    sm = max_raw(sm, dpp_f<0x108>(ninf, sm));
+    const float hi0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 16));
+    const float hi1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 48));
+    if (b < 16) sm = max_raw(sm, lane < 32 ? hi0 : hi1);
+    float m = max_raw(-100.0f, sm);
+    float cur = band_db;
+    const float sd[8] = {sd0.x, sd0.y, sd0.z, sd0.w, sd1.x, sd1.y, sd1.z, sd1.w};
+#pragma unroll
+    for (int d = 1; d <= 8; d++) {
+        if (d == 8) cur = lane == 31 ? ninf : cur;   // channel 0's band 24, seven shifts on: not channel 1's business
+        cur = dpp_f<0x138>(ninf, cur);  // wave_shr:1 -> band_db[lane - d]
+        m = max_raw(m, cur + sd[d - 1]);
+    }
+    const float g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 0));
+    const float g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 32));
+    const float gmax = g0 > g1 ? g0 : g1;
+    if (gmax >= 99.0f) {
+        int dmax = 24;
+        if (gmax < 500.f) {
+            int d = (int)((gmax + 100.0f) * (1.0f / 24.9f)) + 1;
+            dmax = d < 1 ? 1 : (d > 24 ? 24 : d);
+        }
+        const float *srow = reinterpret_cast<const float *>(T.pack + 45 * 64);
+        for (int d = 9; d <= dmax; d++) {
+            cur = dpp_f<0x138>(ninf, cur);
+            if (b < d) cur = ninf;   // came from below band 0 of this channel (the other channel's bands, or nothing)
+            m = max_raw(m, cur + srow[d - 1]);
+        }
+    }
+    return m + (-6.0f);
+}
+
 // amplitude-domain threshold of a masking level s (dB): 10^((smr_thr + fl(s - 10)) / 20), hardware exp2
 __device__ __forceinline__ float masking_amplitude(float s, float smr_thr) {
     const float thr_db = s - 10.0f;

@@ -881,6 +881,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
     const float *pcm = A.pcm + A.clip_off[clip];
 
     float prev[2] = {0.f, 0.f};   // lanes 0..24: temporal masking state of band `lane`, per channel
+                                  // (merged masking pass: prev[0] alone, channel 1's bands on lanes 32..56)
     v2f ae[8], ao[8], be[8], bo[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) ae[r] = ao[r] = splat2(0.f);  // pre-roll: 1024 zeros (encoder.rs:177)
@@ -918,6 +919,48 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         // band statistics, masking level, temporal masking, scale factors (analyse_frame, both channels)
         v2f energy, bmax;
         band_stats_2(ln, c, lds, T, energy, bmax);
+#ifndef FLO_SPLIT_MASK
+        // masking level, temporal step and scale factors of both channels in one pass: channel 0 on lanes 0..24, channel 1
+        // on lanes 32..56 (band_stats_2 leaves every band's totals in both halves)
+        const int bnd = ln & 31, up = ln >> 5;
+        const float rcount = T.pack[26 * 64 + bnd].z;
+        uint32_t sfw1;
+        {
+            const float a = spread_threshold_2(ln, up ? energy.y : energy.x, rcount, T);
+            const float sl = max_raw(a, prev[0] * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
+            prev[0] = sl;
+            const float tl1 = masking_amplitude(sl, T.smr_thr);
+            const float bm = up ? bmax.y : bmax.x;
+            const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
+            sfw1 = sf_word(sfv1);
+            if (bnd < 25) {
+                reinterpret_cast<float *>(&lds.u.a.thr[bnd])[up] = tl1;
+                reinterpret_cast<float *>(&lds.u.a.sf[bnd])[up] = sfv1;
+            }
+        }
+        wave_sync();
+        uint32_t xs[2][8];
+        quantise_2(ln, c, lds, T, xs);
+        if (A.dbg_q) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                uint32_t *dq = reinterpret_cast<uint32_t *>(A.dbg_q + ((frame0 + h) * 2 + ch) * 1024 + 16 * ln);
+#pragma unroll
+                for (int k = 0; k < 8; k++) dq[k] = xs[ch][k];
+            }
+        }
+        if (A.dbg_sfw && bnd < 25) A.dbg_sfw[((frame0 + h) * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
+        wait_counter(&cs.consumed, fbase + h);   // the packer has taken the previous frame out of the hand-over buffer
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            uint4 *dq = reinterpret_cast<uint4 *>(cs.qh[ch]);
+            dq[ln] = make_uint4(xs[ch][0], xs[ch][1], xs[ch][2], xs[ch][3]);
+            dq[64 + ln] = make_uint4(xs[ch][4], xs[ch][5], xs[ch][6], xs[ch][7]);
+        }
+        if (bnd < 25) cs.sfwh[up][bnd] = (uint16_t)sfw1;
+        set_counter(&cs.ready[0], fbase + h + 1);
+        set_counter(&cs.ready[1], fbase + h + 1);
+#else
         const float rcount = T.pack[26 * 64 + ln].z;
         uint32_t sfw[2];
         float tl[2], sfv[2];
@@ -960,6 +1003,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         }
         set_counter(&cs.ready[0], fbase + h + 1);
         set_counter(&cs.ready[1], fbase + h + 1);
+#endif
     };
     for (unsigned h = 0; h < hops; h += 2) {
         frame_body(h, ae, ao, be, bo);
