@@ -959,6 +959,7 @@ __device__ __forceinline__ void quantise_2(const int lane, const v2f (&c)[16], c
                               __uint_as_float((__float_as_uint(xsc.y) & 0x80000000u) | 0x3EFFFFFFu)};
             const v2f rs = xsc + half;
             const float t0 = max_raw(th[k].x, al[k]), t1 = max_raw(th[k].y, al[k]);
+            // (compare + select instead of the sign mask was measured: 62 fewer vector, 188 more scalar instructions, 1.4 % slower)
             const int m0 = __float_as_int(t0 - fabsf(x.x)) >> 31, m1 = __float_as_int(t1 - fabsf(x.y)) >> 31;
             v[0][k] = cvt_rz(rs.x) & m0;
             v[1][k] = cvt_rz(rs.y) & m1;

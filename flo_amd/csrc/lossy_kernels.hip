@@ -886,8 +886,14 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
 #pragma unroll
     for (int r = 0; r < 8; r++) ae[r] = ao[r] = splat2(0.f);  // pre-roll: 1024 zeros (encoder.rs:177)
     if (!A.in_coeffs) load_half_fast_2(lane_id_opaque(), pcm, 0, be, bo);   // (opaque: keeps 16 address pairs out of loop-invariant registers)
+#ifdef FLO_MARKS   // diagnostic builds: section markers in the assembly listing (they pin the schedule: never shipped)
+#define FLO_MARK(x) asm volatile("; MARK " x ::: "memory")
+#else
+#define FLO_MARK(x)
+#endif
     auto frame_body = [&](const unsigned h, v2f (&pe)[8], v2f (&po)[8], v2f (&ce)[8], v2f (&co)[8]) __attribute__((always_inline)) {
         const int ln = lane_id_opaque();
+        FLO_MARK("frame_begin");
         v2f c[16];
         if (A.in_coeffs) {
 #pragma unroll
@@ -900,12 +906,16 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         } else {
             v2f zr[8], zi[8];
             fold_2(ln, pe, po, ce, co, zr, zi, T);
+            FLO_MARK("fold_done");
             // the older half is dead after the fold: the half-frame after next is loaded into its registers now and
             // consumed at the top of the next call. Unconditional, also behind the last frame (the batch allocates one
             // spare half-frame per clip): see lossy_chain_kernel
             load_half_fast_2(ln, pcm, (long long)(h + 1) * 1024, pe, po);
+            FLO_MARK("prefetch_done");
             fft512_2(ln, zr, zi, lds.u.xch4, T);
+            FLO_MARK("fft_done");
             post_rotate_transpose_2(ln, zr, zi, lds.u.coef2, c, T);
+            FLO_MARK("postrot_done");
 
             if (A.dbg_coeffs) {
 #pragma unroll
@@ -919,6 +929,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         // band statistics, masking level, temporal masking, scale factors (analyse_frame, both channels)
         v2f energy, bmax;
         band_stats_2(ln, c, lds, T, energy, bmax);
+        FLO_MARK("bandstats_done");
 #ifndef FLO_SPLIT_MASK
         // masking level, temporal step and scale factors of both channels in one pass: channel 0 on lanes 0..24, channel 1
         // on lanes 32..56 (band_stats_2 leaves every band's totals in both halves)
@@ -939,8 +950,10 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             }
         }
         wave_sync();
+        FLO_MARK("mask_done");
         uint32_t xs[2][8];
         quantise_2(ln, c, lds, T, xs);
+        FLO_MARK("quant_done");
         if (A.dbg_q) {
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
@@ -960,6 +973,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         if (bnd < 25) cs.sfwh[up][bnd] = (uint16_t)sfw1;
         set_counter(&cs.ready[0], fbase + h + 1);
         set_counter(&cs.ready[1], fbase + h + 1);
+        FLO_MARK("frame_end");
 #else
         const float rcount = T.pack[26 * 64 + ln].z;
         uint32_t sfw[2];
