@@ -882,7 +882,12 @@ struct StereoLds {
 // (there is no packed maximum). Same slots, same order of additions per channel as band_stats<CH>.
 __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16], StereoLds &L, const LossyDevTables &T,
                                              v2f &energy, v2f &bmax) {
-    char *sumb = reinterpret_cast<char *>(L.u.a.sum), *mxb = reinterpret_cast<char *>(L.u.a.mx);
+    // Slot addresses as 32-bit LDS offsets from ONE scalar base: as the sum of the clip's LDS base and the member offset
+    // the compiler re-added both terms for every access (two vector adds per slot instead of one). The accesses go
+    // through address-space-3 pointers so that they stay ds_* instructions.
+    typedef __attribute__((address_space(3))) v2f lds_v2f;
+    const uint32_t sum0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)L.u.a.sum);
+    const uint32_t mxd = (uint32_t)(reinterpret_cast<char *>(L.u.a.mx) - reinterpret_cast<char *>(L.u.a.sum));
     if (lane == 0) {   // the zero slot shares storage with the exchange buffer: written every frame
         L.u.a.sum[kZeroSlot] = make_float2(0.f, 0.f);
         L.u.a.mx[kZeroSlot] = make_float2(0.f, 0.f);
@@ -900,8 +905,9 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
             acc = fma2(c[e], c[e], acc);
             mx.x = max_abs_raw(mx.x, c[e].x);
             mx.y = max_abs_raw(mx.y, c[e].y);
-            *reinterpret_cast<float2 *>(sumb + dv[k]) = make_float2(acc.x, acc.y);
-            *reinterpret_cast<float2 *>(mxb + dv[k]) = make_float2(mx.x, mx.y);
+            const uint32_t a = sum0 + dv[k];
+            *reinterpret_cast<lds_v2f *>((uintptr_t)a) = acc;
+            *reinterpret_cast<lds_v2f *>((uintptr_t)(a + mxd)) = mx;
             acc = acc * splat2(kp[k]);
             mx = mx * splat2(kp[k]);
         }
@@ -913,15 +919,16 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
     for (int g = 0; g < (groups < 3 ? 3 : groups); g++) {
         const float4 lst = g < 6 ? T.pack[(39 + g) * 64 + lane] : T.pack_ext[(g - 6) * 64 + lane];
         const uint32_t so[4] = {__float_as_uint(lst.x), __float_as_uint(lst.y), __float_as_uint(lst.z), __float_as_uint(lst.w)};
-        float2 vs[4], vm[4];
+        v2f vs[4], vm[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            vs[u] = *reinterpret_cast<const float2 *>(sumb + so[u]);
-            vm[u] = *reinterpret_cast<const float2 *>(mxb + so[u]);
+            const uint32_t a = sum0 + so[u];
+            vs[u] = *reinterpret_cast<const lds_v2f *>((uintptr_t)a);
+            vm[u] = *reinterpret_cast<const lds_v2f *>((uintptr_t)(a + mxd));
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            energy = energy + (v2f){vs[u].x, vs[u].y};
+            energy = energy + vs[u];
             bmax.x = max_raw(bmax.x, vm[u].x);
             bmax.y = max_raw(bmax.y, vm[u].y);
         }
