@@ -20,6 +20,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "container.hpp"
 #include "lossless_kernels.hpp"
@@ -426,31 +427,42 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
         unsigned int fm[5];
         for (int l = 0; l <= MAXO; l++) ac[l] = 0;
         for (int o = 0; o < 5; o++) { fs[o] = 0; fm[o] = 0; }
-        for (unsigned int t0 = 0; t0 < n; t0 += tile) {
-            const unsigned int i0 = t0 + threadIdx.x * kRun;
-            if (i0 >= n) continue;
+        // A run in the interior of the plane (everything but a plane's first and last run) needs no bounds test, no
+        // warm-up rule and has zeros nowhere in its window: FULL drops all of that, element by element (it was five
+        // scalar / compare instructions per element and candidate). Partial sums of a run stay in 32 bits.
+        auto run1 = [&](const unsigned int i0, auto FULL) {
+            constexpr bool full = decltype(FULL)::value;
             int w[kWin];
             load_window(i0, w);
             unsigned int D[5][kRun];
             fixed_all(w, i0, D);
+            unsigned int rs[5] = {0, 0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < kRun; j++) {
                 const unsigned int i = i0 + j;
-                if (i >= n) break;
+                if (!full && i >= n) break;
                 if (try_lpc) {
                     const long long si = w[kHist + j];
 #pragma unroll
                     for (int l = 0; l <= MAXO; l++)
-                        if ((unsigned int)l <= i) ac[l] += si * (long long)w[kHist + j - l];
+                        if (full || (unsigned int)l <= i) ac[l] += si * (long long)w[kHist + j - l];
                 }
 #pragma unroll
                 for (int o = 0; o < 5; o++)
                     if (o <= fixed_max) {
                         const unsigned int a = uabs((int)D[o][j]);
-                        fs[o] += a;
+                        rs[o] += a;   // planes hold i16 (mid/side: 17 bits): |r| < 2^22, sixteen of them fit 32 bits
                         fm[o] = fm[o] > a ? fm[o] : a;
                     }
             }
+#pragma unroll
+            for (int o = 0; o < 5; o++) fs[o] += rs[o];
+        };
+        for (unsigned int t0 = 0; t0 < n; t0 += tile) {
+            const unsigned int i0 = t0 + threadIdx.x * kRun;
+            if (i0 >= n) continue;
+            if (i0 >= 16u && i0 + kRun <= n) run1(i0, std::true_type{});
+            else run1(i0, std::false_type{});
         }
         if (try_lpc)
             for (int l = 0; l <= max_order; l++) {
@@ -504,6 +516,16 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
         return (int)((unsigned int)w[kHist + j] - (unsigned int)(int)pred);
     };
 
+    // the same for a run in the interior of the plane: no warm-up (i >= 16 > ord)
+    auto lpc_res_full = [&](const int (&w)[kWin], int j, int ord, const int *coef, int shift) {
+        long long pred = 0;
+#pragma unroll
+        for (int q = 0; q < MAXO; q++)
+            if (q < ord) pred += (long long)coef[q] * (long long)w[kHist + j - 1 - q];
+        pred >>= shift;
+        return (int)((unsigned int)w[kHist + j] - (unsigned int)(int)pred);
+    };
+
     // ---- sweep 2: code lengths of the fixed candidates, statistics of the LPC candidates
     {
         unsigned long long fb[5];
@@ -515,9 +537,8 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
         for (int o = 0; o < NL; o++) { ls[o] = 0; lm[o] = 0; lw[o][0] = lw[o][1] = lw[o][2] = 0; }
         int kf[5];
         for (int o = 0; o < 5; o++) kf[o] = s_k[1 + o];
-        for (unsigned int t0 = 0; t0 < n; t0 += tile) {
-            const unsigned int i0 = t0 + threadIdx.x * kRun;
-            if (i0 >= n) continue;
+        auto run2 = [&](const unsigned int i0, auto FULL) {
+            constexpr bool full = decltype(FULL)::value;
             int w[kWin];
             load_window(i0, w);
             {
@@ -526,12 +547,14 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
 #pragma unroll
                 for (int o = 0; o < 5; o++)
                     if (o <= fixed_max) {
+                        unsigned int rs = 0;   // at most 16 x 255
 #pragma unroll
                         for (int j = 0; j < kRun; j++)
-                            if (i0 + j < n) {
+                            if (full || i0 + j < n) {
                                 unsigned int q = zigzag((int)D[o][j]) >> kf[o];
-                                fb[o] += q < 255u ? q : 255u;
+                                rs += q < 255u ? q : 255u;
                             }
+                        fb[o] += rs;
                     }
             }
             if (try_lpc) {
@@ -543,20 +566,29 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
 #pragma unroll
                     for (int q = 0; q < NL + 4; q++) coef[q] = q < ord ? s_coef[oi][q] : 0;
                     const int sh = s_shift[oi], k0 = s_kw0[oi];
+                    unsigned int rsum = 0;   // |r| <= 1e6 for a candidate that stays valid; a larger one is discarded
+                                             // by its maximum, whatever its sum
 #pragma unroll
                     for (int j = 0; j < kRun; j++)
-                        if (i0 + j < n) {
-                            const int rr = lpc_res(w, i0 + j, j, ord, coef, sh);
+                        if (full || i0 + j < n) {
+                            const int rr = full ? lpc_res_full(w, j, ord, coef, sh) : lpc_res(w, i0 + j, j, ord, coef, sh);
                             const unsigned int a = uabs(rr);
-                            ls[oi] += a;
+                            rsum += a;
                             lm[oi] = lm[oi] > a ? lm[oi] : a;
                             const unsigned int u0 = zigzag(rr) >> k0;
                             lw[oi][0] += u0 < 255u ? u0 : 255u;
                             lw[oi][1] += (u0 >> 1) < 255u ? (u0 >> 1) : 255u;
                             lw[oi][2] += (u0 >> 2) < 255u ? (u0 >> 2) : 255u;
                         }
+                    ls[oi] += rsum;
                 }
             }
+        };
+        for (unsigned int t0 = 0; t0 < n; t0 += tile) {
+            const unsigned int i0 = t0 + threadIdx.x * kRun;
+            if (i0 >= n) continue;
+            if (i0 >= 16u && i0 + kRun <= n) run2(i0, std::true_type{});
+            else run2(i0, std::false_type{});
         }
         for (int o = 0; o <= fixed_max; o++) {
             unsigned long long t = block_sum(fb[o], red64);
@@ -593,9 +625,8 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
         constexpr int NL = kLpcOrders > 0 ? kLpcOrders : 1;
         unsigned long long lb[NL];
         for (int o = 0; o < NL; o++) lb[o] = 0;
-        for (unsigned int t0 = 0; t0 < n; t0 += tile) {
-            const unsigned int i0 = t0 + threadIdx.x * kRun;
-            if (i0 >= n) continue;
+        auto run3 = [&](const unsigned int i0, auto FULL) {
+            constexpr bool full = decltype(FULL)::value;
             int w[kWin];
             load_window(i0, w);
 #pragma unroll
@@ -606,13 +637,22 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
 #pragma unroll
                 for (int q = 0; q < NL + 4; q++) coef[q] = q < ord ? s_coef[oi][q] : 0;
                 const int sh = s_shift[oi], kk = s_k[6 + oi];
+                unsigned int rs = 0;
 #pragma unroll
                 for (int j = 0; j < kRun; j++)
-                    if (i0 + j < n) {
-                        unsigned int q = zigzag(lpc_res(w, i0 + j, j, ord, coef, sh)) >> kk;
-                        lb[oi] += q < 255u ? q : 255u;
+                    if (full || i0 + j < n) {
+                        const int rr = full ? lpc_res_full(w, j, ord, coef, sh) : lpc_res(w, i0 + j, j, ord, coef, sh);
+                        unsigned int q = zigzag(rr) >> kk;
+                        rs += q < 255u ? q : 255u;
                     }
+                lb[oi] += rs;
             }
+        };
+        for (unsigned int t0 = 0; t0 < n; t0 += tile) {
+            const unsigned int i0 = t0 + threadIdx.x * kRun;
+            if (i0 >= n) continue;
+            if (i0 >= 16u && i0 + kRun <= n) run3(i0, std::true_type{});
+            else run3(i0, std::false_type{});
         }
         for (int ord = 5; ord <= max_order; ord++) {
             const int ci = 6 + ord - 5;
