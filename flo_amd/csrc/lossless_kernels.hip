@@ -780,19 +780,20 @@ struct BitSink {
 // order ch.order (lpc.rs:301-359; positions below the order use order i); ORD >= 5: LPC of exactly ORD taps
 // (lpc.rs:279-298: the first ORD samples of the plane are copied, then i64 dot product, arithmetic shift, wrapping
 // subtraction). w holds the 12 samples before the run and the run itself.
-template <int ORD>
+// FULL: a run in the interior of the plane (i0 >= 16, all 16 samples present): no bounds test, no warm-up rule.
+template <int ORD, bool FULL = false>
 __device__ __forceinline__ unsigned long long run_codes(const LLChan &ch, const int (&w)[16 + kMaxOrder], unsigned int i0,
                                                         unsigned int i1, int k, unsigned int (&u)[16]) {
-    unsigned long long bits = 0;
+    unsigned int bits = 0;   // 16 codes of at most 256 + 15 bits
 #pragma unroll
     for (unsigned int j = 0; j < 16; j++) {
         const unsigned int i = i0 + j;
         u[j] = 0;
-        if (i < i1) {
+        if (FULL || i < i1) {
             const int x0 = w[kMaxOrder + j];
             int r;
             if (ORD == 0) {
-                const int oo = ch.order < (int)i ? ch.order : (int)i;
+                const int oo = (FULL || ch.order < (int)i) ? ch.order : (int)i;
                 const long long x1 = w[kMaxOrder + j - 1], x2 = w[kMaxOrder + j - 2], x3 = w[kMaxOrder + j - 3],
                                 x4 = w[kMaxOrder + j - 4];
                 long long v;
@@ -804,7 +805,7 @@ __device__ __forceinline__ unsigned long long run_codes(const LLChan &ch, const 
                     default: v = (long long)x0 - 4ll * x1 + 6ll * x2 - 4ll * x3 + x4; break;
                 }
                 r = (int)(unsigned int)(unsigned long long)v;
-            } else if (i < (unsigned int)ORD) {
+            } else if (!FULL && i < (unsigned int)ORD) {
                 r = x0;
             } else {
                 long long pred = 0;
@@ -883,20 +884,23 @@ __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
             load_run<kMaxOrder>(P, Q, ms, i0, n, w);
             // residuals of the run: one straight-line instantiation per predictor (the choice is uniform over the
             // workgroup), so every tap and every window index is a compile-time constant
+            const bool full = i0 >= 16u && i0 + kPer <= n;   // everything but a plane's first and last run
+#define FLO_RUN_CODES(ORD) bits = full ? run_codes<ORD, true>(ch, w, i0, i1, k, u) : run_codes<ORD, false>(ch, w, i0, i1, k, u)
             if (ch.kind == 1) {
-                bits = run_codes<0>(ch, w, i0, i1, k, u);
+                FLO_RUN_CODES(0);
             } else {
                 switch (ch.order) {
-                    case 5: bits = run_codes<5>(ch, w, i0, i1, k, u); break;
-                    case 6: bits = run_codes<6>(ch, w, i0, i1, k, u); break;
-                    case 7: bits = run_codes<7>(ch, w, i0, i1, k, u); break;
-                    case 8: bits = run_codes<8>(ch, w, i0, i1, k, u); break;
-                    case 9: bits = run_codes<9>(ch, w, i0, i1, k, u); break;
-                    case 10: bits = run_codes<10>(ch, w, i0, i1, k, u); break;
-                    case 11: bits = run_codes<11>(ch, w, i0, i1, k, u); break;
-                    default: bits = run_codes<12>(ch, w, i0, i1, k, u); break;
+                    case 5: FLO_RUN_CODES(5); break;
+                    case 6: FLO_RUN_CODES(6); break;
+                    case 7: FLO_RUN_CODES(7); break;
+                    case 8: FLO_RUN_CODES(8); break;
+                    case 9: FLO_RUN_CODES(9); break;
+                    case 10: FLO_RUN_CODES(10); break;
+                    case 11: FLO_RUN_CODES(11); break;
+                    default: FLO_RUN_CODES(12); break;
                 }
             }
+#undef FLO_RUN_CODES
         }
         __syncthreads();   // the previous tile's readers of sc are done
         sc[threadIdx.x] = bits;
