@@ -422,10 +422,14 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
 
     // ---- sweep 1: autocorrelation lags 0..max_order (lpc.rs:213-221) and fixed-predictor statistics
     {
+        // The autocorrelation products are exact in double precision (|s| <= 2^16: the planes are i16, mid/side 17 bits),
+        // and so is a thread's running sum while it stays below 2^53 (it is flushed into the i64 total long before:
+        // every 2^12 tiles). v_fma_f64 issues at four times the rate of v_mad_i64_i32.
         long long ac[MAXO + 1];
+        double acd[MAXO + 1];
         unsigned long long fs[5];
         unsigned int fm[5];
-        for (int l = 0; l <= MAXO; l++) ac[l] = 0;
+        for (int l = 0; l <= MAXO; l++) { ac[l] = 0; acd[l] = 0.0; }
         for (int o = 0; o < 5; o++) { fs[o] = 0; fm[o] = 0; }
         // A run in the interior of the plane (everything but a plane's first and last run) needs no bounds test, no
         // warm-up rule and has zeros nowhere in its window: FULL drops all of that, element by element (it was five
@@ -437,16 +441,20 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
             unsigned int D[5][kRun];
             fixed_all(w, i0, D);
             unsigned int rs[5] = {0, 0, 0, 0, 0};
+            if (try_lpc) {
+                // (samples in front of the plane and behind its end are zeros in the window: no bounds test needed)
+                double wd[kWin];
+#pragma unroll
+                for (int j = 0; j < kWin; j++) wd[j] = (double)w[j];
+#pragma unroll
+                for (int j = 0; j < kRun; j++)
+#pragma unroll
+                    for (int l = 0; l <= MAXO; l++) acd[l] = fma(wd[kHist + j], wd[kHist + j - l], acd[l]);
+            }
 #pragma unroll
             for (int j = 0; j < kRun; j++) {
                 const unsigned int i = i0 + j;
                 if (!full && i >= n) break;
-                if (try_lpc) {
-                    const long long si = w[kHist + j];
-#pragma unroll
-                    for (int l = 0; l <= MAXO; l++)
-                        if (full || (unsigned int)l <= i) ac[l] += si * (long long)w[kHist + j - l];
-                }
 #pragma unroll
                 for (int o = 0; o < 5; o++)
                     if (o <= fixed_max) {
@@ -458,12 +466,17 @@ __global__ __launch_bounds__(kLLThreads) void ll_analyze_kernel(LLArgs A) {
 #pragma unroll
             for (int o = 0; o < 5; o++) fs[o] += rs[o];
         };
+        unsigned int tiles_done = 0;
         for (unsigned int t0 = 0; t0 < n; t0 += tile) {
             const unsigned int i0 = t0 + threadIdx.x * kRun;
-            if (i0 >= n) continue;
-            if (i0 >= 16u && i0 + kRun <= n) run1(i0, std::true_type{});
-            else run1(i0, std::false_type{});
+            if (i0 < n) {
+                if (i0 >= 16u && i0 + kRun <= n) run1(i0, std::true_type{});
+                else run1(i0, std::false_type{});
+            }
+            if ((++tiles_done & 4095u) == 0u)   // 2^12 tiles x 16 samples x 2^32 < 2^53
+                for (int l = 0; l <= MAXO; l++) { ac[l] += (long long)acd[l]; acd[l] = 0.0; }
         }
+        for (int l = 0; l <= MAXO; l++) ac[l] += (long long)acd[l];
         if (try_lpc)
             for (int l = 0; l <= max_order; l++) {
                 long long t = block_sum(ac[l], redi64);
