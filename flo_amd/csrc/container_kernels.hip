@@ -155,10 +155,13 @@ __global__ __launch_bounds__(kFinThreads) void crc_slices_kernel(FinishArgs A) {
     }
 }
 
-__global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A) {
-    __shared__ uint32_t s_red[kFinThreads / 64];
-    __shared__ unsigned long long s_sum[kFinThreads];
-    __shared__ unsigned long long s_smp[kFinThreads];
+// THREADS: 256 for batches of many clips, 1024 for a few long ones (a 3-minute clip has 7752 TOC entries: at 256 threads a
+// thread wrote 31 of them one after the other and the kernel took 35 us by itself)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void finish_files_kernel(FinishArgs A) {
+    __shared__ uint32_t s_red[THREADS / 64];
+    __shared__ unsigned long long s_sum[THREADS];
+    __shared__ unsigned long long s_smp[THREADS];
     const unsigned clip = blockIdx.x;
     if (clip >= (unsigned)A.n_clips) return;
     const unsigned t = threadIdx.x;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A)
     if ((t & 63) == 0) s_red[t >> 6] = acc;
 
     // TOC: thread t owns a contiguous run of frames; byte offsets and sample counts by a block scan of the run sums
-    const unsigned per = (nf + kFinThreads - 1) / kFinThreads;
+    const unsigned per = (nf + THREADS - 1) / THREADS;
     const unsigned f0 = t * per < nf ? t * per : nf, f1 = f0 + per < nf ? f0 + per : nf;
     const unsigned long long fb = A.clip_frame0[clip];
     unsigned long long bytes = 0, smp = 0;
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A)
     s_sum[t] = bytes;
     s_smp[t] = smp;
     __syncthreads();
-    for (int d = 1; d < kFinThreads; d <<= 1) {   // inclusive Hillis-Steele scans
+    for (int d = 1; d < THREADS; d <<= 1) {   // inclusive Hillis-Steele scans
         const unsigned long long a = t >= (unsigned)d ? s_sum[t - d] : 0, b = t >= (unsigned)d ? s_smp[t - d] : 0;
         __syncthreads();
         s_sum[t] += a;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A)
     }
     if (t == 0) {
         uint32_t r = 0;
-        for (int k = 0; k < kFinThreads / 64; k++) r ^= s_red[k];
+        for (int k = 0; k < THREADS / 64; k++) r ^= s_red[k];
         const uint32_t crc = ~r;
         if (A.crc_out) A.crc_out[clip] = crc;
         // header (writer.rs:132-191)
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(kFinThreads) void finish_files_kernel(FinishArgs A)
         put32(p + 8, A.sample_rate);
         put8(p + 12, A.channels);
         put8(p + 13, A.bit_depth);
-        put64(p + 14, s_smp[kFinThreads - 1]);   // total_samples = sum of frame_samples
+        put64(p + 14, s_smp[THREADS - 1]);   // total_samples = sum of frame_samples
         put8(p + 22, A.level);
         put8(p + 23, 0); put8(p + 24, 0); put8(p + 25, 0);
         put32(p + 26, crc);
@@ -289,7 +292,8 @@ int launch_finish_files(FinishArgs A, hipStream_t s) {
     memcpy(A.byte_pow, bytep, sizeof bytep);
     memcpy(A.stripe_pow, stripep, sizeof stripep);
     hipLaunchKernelGGL(crc_slices_kernel, dim3((unsigned)A.n_clips, A.parts), dim3(kFinThreads), 0, s, A);
-    hipLaunchKernelGGL(finish_files_kernel, dim3((unsigned)A.n_clips), dim3(kFinThreads), 0, s, A);
+    if (A.n_clips < 64) hipLaunchKernelGGL((finish_files_kernel<1024>), dim3((unsigned)A.n_clips), dim3(1024), 0, s, A);
+    else hipLaunchKernelGGL((finish_files_kernel<256>), dim3((unsigned)A.n_clips), dim3(256), 0, s, A);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

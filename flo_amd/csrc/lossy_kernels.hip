@@ -1221,21 +1221,22 @@ __global__ void lossy_compact_kernel(LossyArgs A) {
 }
 
 // exclusive scan of frame sizes inside each clip: one workgroup per clip
-__global__ __launch_bounds__(256) void lossy_frame_offsets_kernel(LossyArgs A) {
-    __shared__ unsigned long long sc[256];
+template <int THREADS>   // 256, or 1024 for a few long clips
+__global__ __launch_bounds__(THREADS) void lossy_frame_offsets_kernel(LossyArgs A) {
+    __shared__ unsigned long long sc[THREADS];
     const unsigned clip = blockIdx.x;
     if (clip >= (unsigned)A.n_clips) return;
     const unsigned long long f0 = A.clip_frame0[clip];
     const unsigned hops = A.clip_hops[clip];
     // thread t owns a contiguous run of frames: run sums, one block scan, then the offsets of the run
     const unsigned t = threadIdx.x;
-    const unsigned per = (hops + 255) / 256;
+    const unsigned per = (hops + THREADS - 1) / THREADS;
     const unsigned h0 = t * per < hops ? t * per : hops, h1 = h0 + per < hops ? h0 + per : hops;
     unsigned long long sum = 0;
     for (unsigned h = h0; h < h1; h++) sum += A.frame_size[f0 + h];
     sc[t] = sum;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
+    for (int d = 1; d < THREADS; d <<= 1) {
         unsigned long long v = t >= (unsigned)d ? sc[t - d] : 0;
         __syncthreads();
         sc[t] += v;
@@ -1246,7 +1247,7 @@ __global__ __launch_bounds__(256) void lossy_frame_offsets_kernel(LossyArgs A) {
         A.frame_off[f0 + h] = off;
         off += A.frame_size[f0 + h];
     }
-    if (t == 255) A.clip_bytes[clip] = sc[255];
+    if (t == THREADS - 1) A.clip_bytes[clip] = sc[THREADS - 1];
 }
 
 // ---------------------------------------------------------------------------------------------- stage kernels
@@ -1489,7 +1490,8 @@ int launch_lossy_scan(const LossyArgs &A, hipStream_t s) {
     return 0;
 }
 int launch_lossy_compact(const LossyArgs &A, hipStream_t s) {
-    hipLaunchKernelGGL(lossy_frame_offsets_kernel, dim3(A.n_clips), dim3(256), 0, s, A);
+    if (A.n_clips < 64) hipLaunchKernelGGL((lossy_frame_offsets_kernel<1024>), dim3(A.n_clips), dim3(1024), 0, s, A);
+    else hipLaunchKernelGGL((lossy_frame_offsets_kernel<256>), dim3(A.n_clips), dim3(256), 0, s, A);
     FLO_LAUNCH_CHECK();
     hipLaunchKernelGGL(lossy_compact_kernel, dim3((unsigned)A.total_frames), dim3(256), 0, s, A);
     FLO_LAUNCH_CHECK();
