@@ -1087,6 +1087,149 @@ __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
     for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
 }
 
+// Stereo frames, shipped quantiser, PCM input: the frame-parallel passes built from the lock-step stereo device
+// functions of lossy_chain2x_kernel (packed f32 transform of both channels, both channels' masking in one pass, ballot
+// packer) - one wave does a frame's transform AND packing here. Same bytes as every other form (tests compare them).
+template <int PASS>
+__global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
+    __shared__ StereoLds lds;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[PASS == 2 ? kFrameCap + 64 + 256 : 16];
+    __shared__ __attribute__((aligned(16))) uint32_t qh[PASS == 2 ? 2 : 1][PASS == 2 ? 512 : 4];
+    __shared__ uint32_t runtab[PASS == 2 ? kRunTabEntries : 1];
+    const int lane = lane_id();
+    const unsigned long long gframe = blockIdx.x;
+    if (gframe >= A.total_frames) return;
+    int lo = 0, hi = A.n_clips - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (A.clip_frame0[mid] <= gframe) lo = mid; else hi = mid - 1;
+    }
+    const unsigned clip = (unsigned)lo;
+    const unsigned h = (unsigned)(gframe - A.clip_frame0[clip]);
+    const float *pcm = A.pcm + A.clip_off[clip];
+    const LossyDevTables &T = A.T;   // constant rows straight from global memory: one frame per wave reads each once
+
+    v2f c[16];
+    {
+        v2f ae[8], ao[8], be[8], bo[8];
+        if (h == 0) {   // pre-roll: 1024 zeros (encoder.rs:177)
+#pragma unroll
+            for (int r = 0; r < 8; r++) ae[r] = ao[r] = splat2(0.f);
+        } else {
+            load_half_fast_2(lane, pcm, (long long)h * 1024 - 1024, ae, ao);
+        }
+        load_half_fast_2(lane, pcm, (long long)h * 1024, be, bo);   // the batch pads every clip: no bounds to check
+        v2f zr[8], zi[8];
+        fold_2(lane, ae, ao, be, bo, zr, zi, T);
+        fft512_2(lane, zr, zi, lds.u.xch4, T);
+        post_rotate_transpose_2(lane, zr, zi, lds.u.coef2, c, T);
+    }
+    if (PASS == 2 && A.dbg_coeffs) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            float *d = A.dbg_coeffs + (gframe * 2 + ch) * 1024 + 16 * lane;
+#pragma unroll
+            for (int e = 0; e < 16; e++) d[e] = ch ? c[e].y : c[e].x;
+        }
+    }
+    v2f energy, bmax;
+    band_stats_2(lane, c, lds, T, energy, bmax);
+    const int bnd = lane & 31, up = lane >> 5;
+    const float rcount = T.pack[26 * 64 + bnd].z;
+    const float a = spread_threshold_2(lane, up ? energy.y : energy.x, rcount, T);
+    if (PASS == 1) {
+        if (bnd < 25) A.a_t[(gframe * 2 + up) * 32 + bnd] = a;
+        return;
+    }
+    const float prev = bnd < 25 ? A.s_prev[(gframe * 2 + up) * 32 + bnd] : 0.f;
+    const float sl = max_raw(a, prev * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
+    const float tl1 = masking_amplitude(sl, T.smr_thr);
+    const float bm = up ? bmax.y : bmax.x;
+    const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
+    const uint32_t sfw1 = sf_word(sfv1);
+    if (bnd < 25) {
+        reinterpret_cast<float *>(&lds.u.a.thr[bnd])[up] = tl1;
+        reinterpret_cast<float *>(&lds.u.a.sf[bnd])[up] = sfv1;
+    }
+    wave_sync();
+    uint32_t xs[2][8];
+    quantise_2(lane, c, lds, T, xs);
+    if (A.dbg_q) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            uint32_t *dq = reinterpret_cast<uint32_t *>(A.dbg_q + (gframe * 2 + ch) * 1024 + 16 * lane);
+#pragma unroll
+            for (int k = 0; k < 8; k++) dq[k] = xs[ch][k];
+        }
+    }
+    if (A.dbg_sfw && bnd < 25) A.dbg_sfw[(gframe * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
+
+    // ---- packing: the ballot form wants value 64 e + lane in register e: one trip through LDS re-deals the integers
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+        uint4 *dq = reinterpret_cast<uint4 *>(qh[ch]);
+        dq[lane] = make_uint4(xs[ch][0], xs[ch][1], xs[ch][2], xs[ch][3]);
+        dq[64 + lane] = make_uint4(xs[ch][4], xs[ch][5], xs[ch][6], xs[ch][7]);
+    }
+    wave_sync();
+    uint32_t x[2][16];
+    const uint32_t hw0 = 8u * ((uint32_t)lane >> 4) + ((uint32_t)lane & 7u) + 512u * (((uint32_t)lane >> 3) & 1u);
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+        const uint16_t *hv = reinterpret_cast<const uint16_t *>(qh[ch]);
+#pragma unroll
+        for (int e = 0; e < 16; e++) x[ch][e] = hv[hw0 + 32u * (uint32_t)e];
+    }
+    uint8_t *f = stage;
+    const uint32_t f_a = (uint32_t)(uintptr_t)f, tab_a = (uint32_t)(uintptr_t)runtab;
+    if (bnd < 25) {
+        uint8_t *p = f + 12 + 50 * up + 2 * bnd;
+        lds_st8<0>(p, sfw1);
+        lds_st8<1>(p, sfw1 >> 8);
+    }
+    uint32_t pos = 112;   // 12 + 50 * 2: length word of channel 0
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+        uint32_t t = sparse_ballot_pack(lane, x[ch], f_a + pos + 4u, tab_a);
+        if (t == kSparseFallback) {   // uniform: dense frame (a run longer than 255, or more than 126 runs)
+            int q[1][16];
+            uint32_t hi16[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                hi16[k] = xs[ch][k] >> 16;
+                q[0][2 * k] = (int)xs[ch][k];
+                q[0][2 * k + 1] = (int)hi16[k];
+            }
+            SparsePlan P[1];
+            sparse_plan_m(lane, nonzero_mask16_packed(xs[ch], hi16), P[0]);
+            uint8_t *const dsts[1] = {f + pos + 4};
+            const uint32_t trash[1] = {(uint32_t)((stage + kFrameCap + 64 + 2 * lane) - dsts[0])};
+            sparse_emit_n<1>(lane, q, P, dsts, trash);
+            t = P[0].total;
+        }
+        if (lane == 32 + ch) {
+            uint8_t *p = f + pos;
+            p[0] = (uint8_t)t; p[1] = (uint8_t)(t >> 8); p[2] = (uint8_t)(t >> 16); p[3] = (uint8_t)(t >> 24);
+        }
+        pos += 4u + t;
+    }
+    const uint32_t flen = pos, blob_len = flen - 10;
+    if (lane == 0) {
+        f[0] = 253;
+        f[1] = 0x00; f[2] = 0x04; f[3] = 0; f[4] = 0;  // frame_samples = 1024
+        f[5] = 0;
+        f[6] = (uint8_t)blob_len; f[7] = (uint8_t)(blob_len >> 8); f[8] = (uint8_t)(blob_len >> 16); f[9] = (uint8_t)(blob_len >> 24);
+        f[10] = 0;  // BlockSize::Long
+        f[11] = 2;
+        A.frame_size[gframe] = flen;
+    }
+    wave_sync();
+    const uint32_t n16 = (flen + 15) >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(stage);
+    uint4 *dst = reinterpret_cast<uint4 *>(A.slots + gframe * (unsigned long long)A.slot_bytes);
+    for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
+}
+
 // Any channel count up to kMaxLossyChannels: one wave per frame walks the channels one after the other with the
 // single-channel device functions. Pass 2 parks every channel's integers (i16) in LDS because the byte position of a
 // channel's sparse blob depends on the sizes of the channels before it, then plans again and emits in channel order.
@@ -1470,6 +1613,9 @@ int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s) {
         if (pass == 1) hipLaunchKernelGGL((lossy_frame_kernel<1, 1, false>), g, b, 0, s, A);
         else if (A.exact) hipLaunchKernelGGL((lossy_frame_kernel<1, 2, true>), g, b, 0, s, A);
         else hipLaunchKernelGGL((lossy_frame_kernel<1, 2, false>), g, b, 0, s, A);
+    } else if (A.nch == 2 && !A.exact && !A.in_coeffs && !getenv("FLO_FRAME_OLD")) {
+        if (pass == 1) hipLaunchKernelGGL((lossy_frame2x_kernel<1>), g, b, 0, s, A);
+        else hipLaunchKernelGGL((lossy_frame2x_kernel<2>), g, b, 0, s, A);
     } else if (A.nch == 2) {
         if (pass == 1) hipLaunchKernelGGL((lossy_frame_kernel<2, 1, false>), g, b, 0, s, A);
         else if (A.exact) hipLaunchKernelGGL((lossy_frame_kernel<2, 2, true>), g, b, 0, s, A);
