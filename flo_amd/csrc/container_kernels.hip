@@ -247,7 +247,7 @@ __global__ __launch_bounds__(THREADS) void finish_files_kernel(FinishArgs A) {
 
 int launch_finish_files(FinishArgs A, hipStream_t s) {
     if (!A.n_clips) return 0;
-    if (A.parts < 1 || A.parts > 128 || !A.part_reg) return -1;
+    if (A.parts < 1 || A.parts > (A.n_clips < 64 ? 512u : 128u) || !A.part_reg) return -1;
     static unsigned int pow2[40], blk[256], bytep[64], stripep[256];
     static std::vector<unsigned int> host_tables;
     static std::mutex mu;

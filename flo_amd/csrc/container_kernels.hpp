@@ -32,11 +32,13 @@ struct FinishArgs {
 };
 
 int launch_finish_files(FinishArgs A, hipStream_t s);
-// slices per clip so that about two thousand workgroups run, at most 128
+// slices per clip so that about two thousand workgroups run; at most 128, or 512 for the few-long-clips case whose
+// finish_files_kernel runs 1024 threads (one per slice register)
 inline unsigned finish_parts_for(size_t n_clips) {
     if (n_clips >= 1024) return 1;
     size_t p = (2048 + n_clips - 1) / (n_clips ? n_clips : 1);
-    return (unsigned)(p > 128 ? 128 : p);
+    const size_t cap = n_clips < 64 ? 512 : 128;
+    return (unsigned)(p > cap ? cap : p);
 }
 
 }  // namespace flo
