@@ -205,16 +205,31 @@ __global__ __launch_bounds__(THREADS) void finish_files_kernel(FinishArgs A) {
     }
     {
         unsigned long long off = s_sum[t] - bytes, cum = s_smp[t] - smp;
-        uint8_t *toc = file + 70 + 4;
+        // The DATA chunk is 16-byte aligned and the TOC ends right in front of it, 20 bytes per entry: every entry is
+        // 4-byte aligned, five dword stores. The timestamp floor(cum * 1000 / rate) is carried as quotient and
+        // remainder from entry to entry (one 64-bit division per thread, 32-bit ones after it where they suffice).
+        uint32_t *toc = reinterpret_cast<uint32_t *>(file + 70 + 4);
+        const unsigned long long rate = A.sample_rate;
+        unsigned long long q = cum * 1000ull / rate, r = cum * 1000ull - q * rate;
         for (unsigned f = f0; f < f1; f++) {   // writer.rs:193-224: index, byte offset, size, timestamp in ms
-            uint8_t *e = toc + 20ull * f;
+            uint32_t *e = toc + 5ull * f;
             const unsigned fs = A.frame_size[fb + f];
-            put32(e, f);
-            put64(e + 4, off);
-            put32(e + 12, fs);
-            put32(e + 16, (uint32_t)(cum * 1000ull / (unsigned long long)A.sample_rate));
+            e[0] = f;
+            e[1] = (uint32_t)off;
+            e[2] = (uint32_t)(off >> 32);
+            e[3] = fs;
+            e[4] = (uint32_t)q;
             off += fs;
-            cum += A.frame_samples ? A.frame_samples[fb + f] : A.const_samples;
+            const unsigned long long add = (unsigned long long)(A.frame_samples ? A.frame_samples[fb + f] : A.const_samples) * 1000ull + r;
+            if (add < 0x100000000ull) {
+                const uint32_t a32 = (uint32_t)add, r32 = (uint32_t)rate, dq = a32 / r32;
+                q += dq;
+                r = a32 - dq * r32;
+            } else {
+                const unsigned long long dq = add / rate;
+                q += dq;
+                r = add - dq * rate;
+            }
         }
     }
     if (t == 0) {
