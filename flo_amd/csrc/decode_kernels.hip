@@ -100,8 +100,63 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
                     sf[lane] = wv > 0 ? powf(2.0f, ((float)wv - 32768.0f) / 256.0f) : 0.0f;
                 }
                 for (int i = lane; i < 1024; i += 64) q[i] = 0;
-                // deserialize_sparse (decoder.rs:134-167): lane 0 walks the record headers, then every lane copies records
-                if (lane == 0) {
+                // deserialize_sparse (decoder.rs:134-167). The record headers form a chain (a record starts where the
+                // previous one ends), so one lane has to follow it - but what it finds at a position does not depend on
+                // how it got there: every lane first parses "a record starting here" for its share of the byte
+                // positions (varint, count, length) into a table, and the chain walk is then ONE dependent LDS read per
+                // record instead of three to five byte reads. The table borrows `recon`, which is idle until the inverse
+                // transform; blobs beyond its 2048 entries (or walked in place) keep the byte-wise walk.
+                const bool tabled = sp == sblob && blen <= 2048u;
+                uint32_t *ptab = reinterpret_cast<uint32_t *>(recon);
+                if (tabled) {
+                    for (uint32_t p0 = (uint32_t)lane; p0 < blen; p0 += 64u) {
+                        uint32_t p = p0, value = 0, shift = 0;
+                        while (p < blen) {   // decode_varint (:170-188)
+                            const uint32_t b = sp[p++];
+                            value |= (b & 0x7Fu) << shift;
+                            if (!(b & 0x80u)) break;
+                            shift += 7;
+                            if (shift >= 32) break;
+                        }
+                        // entry: zero run (clamped: anything >= 1024 ends the walk) | count << 11 | bytes to the next
+                        // record << 19 | "no count byte" << 30
+                        uint32_t e = value < 2047u ? value : 2047u;
+                        if (p >= blen) {
+                            e |= 1u << 30;
+                        } else {
+                            const uint32_t nz = sp[p++];
+                            const uint32_t avail = (blen - p) >> 1;
+                            const uint32_t cnt = nz < avail ? nz : avail;
+                            e |= (cnt << 11) | ((p + 2u * cnt - p0) << 19);
+                        }
+                        ptab[p0] = e;
+                    }
+                    __syncthreads();
+                }
+#ifdef FLO_DEC_ABLATE   // diagnostic: timing without the record walk (results invalid)
+                if (lane == 0) s_nrec = 0;
+                if (false) {
+#else
+                if (lane == 0 && tabled) {
+                    uint32_t p = 0, nrec = 0, oi = 0;
+                    while (p < blen && oi < 1024u) {
+                        const uint32_t e = ptab[p];
+                        oi += e & 2047u;
+                        if (e >> 30) break;
+                        const uint32_t cnt_a = (e >> 11) & 255u, adv = (e >> 19) & 2047u;
+                        const uint32_t room = oi < 1024u ? 1024u - oi : 0u;
+                        const uint32_t cnt = cnt_a < room ? cnt_a : room;
+                        if (cnt && nrec < kMaxRecords) {
+                            rec_pos[nrec] = oi | (cnt << 16);
+                            rec_src[nrec] = p + adv - 2u * cnt_a;
+                            nrec++;
+                        }
+                        p += adv;      // (a count cut by `room` ends the walk: oi reaches 1024)
+                        oi += cnt;
+                    }
+                    s_nrec = (int)nrec;
+                } else if (lane == 0) {
+#endif
                     uint32_t p = 0, nrec = 0;
                     unsigned long long oi = 0;
                     while (p < blen && oi < 1024) {
