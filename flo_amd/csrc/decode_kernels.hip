@@ -28,12 +28,16 @@ constexpr int kDecRun = 8;
 constexpr int kBlobStage = 2304;
 
 __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
-    __shared__ short q[1024];
-    __shared__ float xch[1][kXchFloats];
-    __shared__ float recon[2048];
+    // One 8 KiB buffer serves three phases of a channel-frame in turn: the parse table of the record headers, then the
+    // integers + the FFT exchange buffer, then the windowed output. (Apart they were 29.6 KiB per wave: five waves per
+    // CU; now 18.8 KiB: eight.)
+    __shared__ __attribute__((aligned(16))) float u1[2048];
+    short *const q = reinterpret_cast<short *>(u1);                                               // [1024]
+    float (*const xch)[kXchFloats] = reinterpret_cast<float (*)[kXchFloats]>(u1 + 512);          // behind q
+    float *const recon = u1;                                                                      // [2048]
+    static_assert(512 * 4 + kXchFloats * 4 <= 2048 * 4, "q and the exchange buffer share the 8 KiB with room to spare");
     __shared__ float prev[1024];                // second half of the previous frame of the channel being walked
-    __shared__ uint32_t rec_pos[kMaxRecords];   // output index | count << 16 (count <= 255, index < 1024)
-    __shared__ uint32_t rec_src[kMaxRecords];   // byte position of the record's first value
+    __shared__ uint32_t rec[kMaxRecords];       // output index | count << 10 | byte position of the first value << 18
     __shared__ float sf[32];
     __shared__ int s_nrec;
     __shared__ __attribute__((aligned(16))) uint8_t sblob[kBlobStage + 16];   // the channel's sparse bytes, staged
@@ -99,7 +103,6 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
                     const uint32_t wv = rd_u16(data + 2 + 50 * c + 2 * lane);
                     sf[lane] = wv > 0 ? powf(2.0f, ((float)wv - 32768.0f) / 256.0f) : 0.0f;
                 }
-                for (int i = lane; i < 1024; i += 64) q[i] = 0;
                 // deserialize_sparse (decoder.rs:134-167). The record headers form a chain (a record starts where the
                 // previous one ends), so one lane has to follow it - but what it finds at a position does not depend on
                 // how it got there: every lane first parses "a record starting here" for its share of the byte
@@ -135,7 +138,6 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
                 }
 #ifdef FLO_DEC_ABLATE   // diagnostic: timing without the record walk (results invalid)
                 if (lane == 0) s_nrec = 0;
-                if (false) {
 #else
                 if (lane == 0 && tabled) {
                     uint32_t p = 0, nrec = 0, oi = 0;
@@ -147,49 +149,53 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
                         const uint32_t room = oi < 1024u ? 1024u - oi : 0u;
                         const uint32_t cnt = cnt_a < room ? cnt_a : room;
                         if (cnt && nrec < kMaxRecords) {
-                            rec_pos[nrec] = oi | (cnt << 16);
-                            rec_src[nrec] = p + adv - 2u * cnt_a;
+                            rec[nrec] = oi | (cnt << 10) | ((p + adv - 2u * cnt_a) << 18);
                             nrec++;
                         }
                         p += adv;      // (a count cut by `room` ends the walk: oi reaches 1024)
                         oi += cnt;
                     }
                     s_nrec = (int)nrec;
-                } else if (lane == 0) {
-#endif
-                    uint32_t p = 0, nrec = 0;
-                    unsigned long long oi = 0;
-                    while (p < blen && oi < 1024) {
-                        uint32_t value = 0, shift = 0;
-                        while (p < blen) {   // decode_varint (:170-188)
-                            const uint32_t b = sp[p++];
-                            value |= (b & 0x7Fu) << shift;
-                            if (!(b & 0x80u)) break;
-                            shift += 7;
-                            if (shift >= 32) break;
-                        }
-                        oi += value;
-                        if (p >= blen) break;
-                        const uint32_t nz = sp[p++];
-                        const uint32_t avail = (blen - p) >> 1;
-                        const uint32_t room = oi < 1024 ? (uint32_t)(1024 - oi) : 0u;
-                        uint32_t cnt = nz < avail ? nz : avail;
-                        cnt = cnt < room ? cnt : room;
-                        if (cnt && nrec < kMaxRecords) {
-                            rec_pos[nrec] = (uint32_t)oi | (cnt << 16);
-                            rec_src[nrec] = p;
-                            nrec++;
-                        }
-                        p += 2 * cnt;
-                        oi += cnt;
-                    }
-                    s_nrec = (int)nrec;
                 }
-                __syncthreads();
-                for (int r = lane; r < s_nrec; r += 64) {
-                    const uint32_t o = rec_pos[r] & 0xFFFFu, cnt = rec_pos[r] >> 16;
-                    const uint8_t *v = sp + rec_src[r];
-                    for (uint32_t i = 0; i < cnt; i++) q[o + i] = (short)rd_u16(v + 2 * i);
+#endif
+                if (tabled) {
+                    __syncthreads();                                   // the table is dead: its memory becomes q
+                    for (int i = lane; i < 1024; i += 64) q[i] = 0;
+                    __syncthreads();
+                    for (int r = lane; r < s_nrec; r += 64) {
+                        const uint32_t o = rec[r] & 1023u, cnt = (rec[r] >> 10) & 255u;
+                        const uint8_t *v = sp + (rec[r] >> 18);
+                        for (uint32_t i = 0; i < cnt; i++) q[o + i] = (short)rd_u16(v + 2 * i);
+                    }
+                } else {
+                    // a blob too long for the table (or walked in place): outside what the encoder produces. One lane
+                    // walks it byte by byte and places the values itself.
+                    for (int i = lane; i < 1024; i += 64) q[i] = 0;
+                    __syncthreads();
+                    if (lane == 0) {
+                        uint32_t p = 0;
+                        unsigned long long oi = 0;
+                        while (p < blen && oi < 1024) {
+                            uint32_t value = 0, shift = 0;
+                            while (p < blen) {   // decode_varint (:170-188)
+                                const uint32_t b = sp[p++];
+                                value |= (b & 0x7Fu) << shift;
+                                if (!(b & 0x80u)) break;
+                                shift += 7;
+                                if (shift >= 32) break;
+                            }
+                            oi += value;
+                            if (p >= blen) break;
+                            const uint32_t nz = sp[p++];
+                            const uint32_t avail = (blen - p) >> 1;
+                            const uint32_t room = oi < 1024 ? (uint32_t)(1024 - oi) : 0u;
+                            uint32_t cnt = nz < avail ? nz : avail;
+                            cnt = cnt < room ? cnt : room;
+                            for (uint32_t i = 0; i < cnt; i++) q[(uint32_t)oi + i] = (short)rd_u16(sp + p + 2 * i);
+                            p += 2 * cnt;
+                            oi += cnt;
+                        }
+                    }
                 }
                 __syncthreads();
                 // dequantise (decoder.rs:35-48) straight into the inverse transform's pre-rotation (mdct.rs:238-247)
