@@ -253,6 +253,26 @@ def main():
         if sk_n:
             out["shard_1250"]["kernel_ms"] = round(sk_ms / sk_n, 4)
             out["shard_1250"]["roofline_frac"] = round(ALG_BYTES_PER_SAMPLE * 1250 * n_il / (sk_ms / sk_n / 1e3) / 1e9 / HBM_PEAK_GBS, 4)
+        # decode of the same batch from its bitstreams in HBM into device memory (flo_batch_decode: lossy_decode_kernel).
+        # Algorithmic bytes: the compressed files in + 4 B of f32 PCM out per sample.
+        hops = (n_sf + 1024 + 1023) // 1024
+        dec_n = 1250 * (hops - 1) * 1024 * ch
+        dst = torch.empty(dec_n, dtype=torch.float32, device=f"cuda:{local_rank}")
+        torch.cuda.synchronize()
+        bs.decode_to(dst.data_ptr(), dst.numel())
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(3):
+            bs.decode_to(dst.data_ptr(), dst.numel())
+        ctx.profile_enable(False)
+        dk_ms, dk_n = ctx.profile_query("lossy_decode")
+        if dk_n:
+            dms = dk_ms / dk_n
+            dbytes = 4.0 * dec_n + bs.data_bytes()
+            out["shard_1250"]["decode"] = {"kernel_ms": round(dms, 3), "value": round(1250 * n_il / dms / 1e3, 1), "unit": "Msamples/s",
+                                           "hbm_algorithmic_GBs": round(dbytes / (dms / 1e3) / 1e9, 1),
+                                           "frac_of_hbm_peak": round(dbytes / (dms / 1e3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del dst
         bs.close()
 
     if not args.no_single_clip and world == 1:
