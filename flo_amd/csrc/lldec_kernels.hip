@@ -47,6 +47,38 @@ __device__ __forceinline__ uint32_t be_word(const uint8_t *p, uint32_t len, uint
     if (b + 2u < len) v |= (uint32_t)p[b + 2] << 8;
     return v;
 }
+// Stage big-endian words [w0, w0 + count) of a stream into LDS through `put(i, word)`, eight loads in flight per lane:
+// one load at a time costs a memory round trip each, and that was most of what these kernels did.
+template <class Put>
+__device__ __forceinline__ void stage_words(const uint8_t *p, uint32_t len, uint32_t w0, int count, int lane, Put put) {
+    constexpr int U = 8;
+    for (int base = 0; base < count; base += 64 * U) {
+        uint32_t v[U];
+        const bool whole = base + 64 * U <= count && 4ull * (w0 + (uint32_t)base + 64u * U) + 4ull <= (unsigned long long)len;   // uniform
+        if (whole) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                uint32_t x;
+                __builtin_memcpy(&x, p + 4ull * (w0 + (uint32_t)(base + 64 * u + lane)), 4);
+                v[u] = __builtin_bswap32(x);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) put(base + 64 * u + lane, v[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = base + 64 * u + lane;
+                v[u] = i < count ? be_word(p, len, w0 + (uint32_t)i) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = base + 64 * u + lane;
+                if (i < count) put(i, v[u]);
+            }
+        }
+    }
+}
+
 // the 32 bits that start at bit `pos` of a big-endian word array
 __device__ __forceinline__ uint32_t window32(const uint32_t *w, uint32_t pos) {
     const uint32_t i = pos >> 5, sh = pos & 31u;
@@ -71,10 +103,13 @@ __global__ __launch_bounds__(64) void ll_rice_scan_kernel(LlParArgs A) {
     const int lane = (int)threadIdx.x;
     const LlChannelDev c = A.ch[ch];
     const uint8_t *p = A.bytes + c.off;
-    for (int i = lane; i < kScanTiles * kScanStride; i += 64) {
-        const int tile = i / kScanStride, w = i - tile * kScanStride;
-        words[i] = be_word(p, c.len, (t0 + tile) * kTileWords + w);
-    }
+    // the four tiles are consecutive words of the stream: word i of the wave goes to tile i / 64 (the two spare words
+    // of a tile's row repeat the next tile's first two)
+    stage_words(p, c.len, t0 * kTileWords, kScanTiles * kTileWords + 2, lane, [&](int i, uint32_t v) {
+        const int tile = i >> 6, w = i & 63;
+        if (tile < kScanTiles) words[tile * kScanStride + w] = v;
+        if (w < 2 && tile > 0) words[(tile - 1) * kScanStride + kTileWords + w] = v;
+    });
     __syncthreads();
     const uint32_t k = c.rice_k;
     const uint32_t tile = (uint32_t)lane >> 4, st = (uint32_t)lane & 15u;
@@ -152,7 +187,7 @@ __global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
     const int lane = (int)threadIdx.x;
     const LlChannelDev c = A.ch[ch];
     const uint8_t *p = A.bytes + c.off;
-    for (int i = lane; i < 64 * kTileWords + kDecOver; i += 64) words[i + (i >> 6)] = be_word(p, c.len, t0 * kTileWords + i);
+    stage_words(p, c.len, t0 * kTileWords, 64 * kTileWords + kDecOver, lane, [&](int i, uint32_t v) { words[i + (i >> 6)] = v; });
     __syncthreads();
     const unsigned t = t0 + lane;
     if (t >= nt) return;
