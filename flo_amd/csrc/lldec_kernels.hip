@@ -115,29 +115,26 @@ __global__ __launch_bounds__(64) void ll_rice_scan_kernel(LlParArgs A) {
     const uint32_t tile = (uint32_t)lane >> 4, st = (uint32_t)lane & 15u;
     if (st > k + 1u || t0 + tile >= nt) return;
     const uint32_t *w = words + tile * kScanStride;
-    uint32_t pos = st <= k ? st : 0u, n = 0, exit_state;
-    bool inside = st == k + 1u;   // entered in the middle of a unary run: that code was counted where it started
-    for (;;) {
-        if (pos >= (uint32_t)kRiceTileBits) {
-            exit_state = pos - kRiceTileBits;
-            break;
-        }
-        if (!inside) n++;
-        inside = false;
-        bool found = false;
-        while (pos < (uint32_t)kRiceTileBits) {
-            const uint32_t ones = leading_ones(window32(w, pos));
-            pos += ones;
-            if (ones < 32u) {
-                found = true;
-                break;
-            }
-        }
-        if (!found || pos >= (uint32_t)kRiceTileBits) {   // the terminating 0 belongs to a later tile
-            exit_state = k + 1u;
-            break;
-        }
-        pos += 1u + k;
+    // One loop iteration per lane = one look at the 32 bits at `pos`, where the terminator of the current code (already
+    // counted) is being searched: either the window is all ones (32 bits further, still inside the run) or it shows
+    // the terminating 0, behind which k remainder bits are skipped and - if that is still inside the tile - the next
+    // code starts. Straight-line, predicated by `active`: nested data-dependent loops cost more in exec-mask
+    // bookkeeping than in arithmetic.
+    uint32_t pos = st <= k ? st : 0u, n = st <= k ? 1u : 0u, exit_state = k + 1u;
+    bool active = true;
+    while (__ballot(active) != 0ull) {
+        const uint32_t rp = active ? pos : 0u;
+        const uint32_t ones = leading_ones(window32(w, rp));
+        const uint32_t z = rp + ones;                       // the terminating 0, or 32 bits on
+        const bool term = ones < 32u && z < (uint32_t)kRiceTileBits;
+        const uint32_t nxt = term ? z + 1u + k : z;
+        const bool leaves = nxt >= (uint32_t)kRiceTileBits;
+        // leaving behind a terminator: 0..k bits into the next tile; leaving inside a run: the run goes on there
+        const bool out = active && leaves;
+        exit_state = out ? (term ? nxt - (uint32_t)kRiceTileBits : k + 1u) : exit_state;
+        n += (active && !leaves && term) ? 1u : 0u;
+        pos = active ? nxt : pos;
+        active = active && !leaves;
     }
     A.tabs[(size_t)(A.tile0[ch] + t0 + tile) * kRiceStates + st] = exit_state | (n << 5);
 }
