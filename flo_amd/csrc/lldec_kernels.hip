@@ -199,39 +199,38 @@ __global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
     };
     const uint32_t tile_lo = (uint32_t)lane * kRiceTileBits, tile_hi = tile_lo + kRiceTileBits;
     const uint32_t limit = 64u * kRiceTileBits + 32u * (kDecOver - 2);   // staged bits a run may be followed through
-    uint32_t pos = tile_lo, idx = e.x;
-    if (e.y == k + 1u) {   // finish the run that was under way, then skip the remainder bits
-        bool found = false;
-        while (pos < tile_hi) {
-            const uint32_t ones = leading_ones(win(pos));
-            pos += ones;
-            if (ones < 32u) {
-                found = true;
-                break;
-            }
+    // One predicated loop, one look at a 32-bit window per iteration (see ll_rice_scan_kernel). `skip`: the run under
+    // way when the tile was entered belongs to a code of an earlier tile - it is followed to its terminator inside this
+    // tile (or the tile holds no code start at all) and produces no value here.
+    bool skip = e.y == k + 1u, active = true, escape = false;
+    uint32_t pos = tile_lo + (skip ? 0u : e.y), idx = e.x, q = 0;
+    active = skip || (pos < tile_hi && idx < n);
+    while (__ballot(active) != 0ull) {
+        const uint32_t rp = active ? pos : tile_lo;
+        const uint32_t ones = leading_ones(win(rp));
+        const uint32_t z = rp + ones, q2 = q + ones;
+        const bool term = ones < 32u;
+        // our own code: the 256-ones escape (rice.rs:134-139), or a run past what is staged -> the serial reader
+        const bool esc = !skip && (q2 >= 256u || z >= limit);
+        // an inherited run must end inside the tile
+        const bool lost = skip && (z >= tile_hi);
+        const uint32_t rem = k ? win((active && term && !esc) ? z + 1u : tile_lo) >> (32u - k) : 0u;
+        const bool emit = active && term && !skip && !esc;
+        if (emit) {
+            const uint32_t u = (q2 << k) | rem;
+            out[idx] = (int)(u >> 1) ^ -(int)(u & 1u);
         }
-        if (!found || pos >= tile_hi) return;
-        pos += 1u + k;
-    } else {
-        pos += e.y;
+        const uint32_t npos = term ? z + 1u + k : z;
+        const uint32_t nidx = idx + (emit ? 1u : 0u);
+        escape = escape || (active && esc);
+        const bool go_on = !esc && !lost && (term ? (npos < tile_hi && nidx < n) : true);
+        pos = active ? npos : pos;
+        idx = active ? nidx : idx;
+        q = term ? 0u : q2;
+        skip = skip && !term;
+        active = active && go_on;
     }
-    while (pos < tile_hi && idx < n) {
-        uint32_t q = 0;
-        for (;;) {
-            const uint32_t ones = leading_ones(win(pos));
-            q += ones;
-            pos += ones;
-            if (ones < 32u || q >= 256u || pos >= limit) break;
-        }
-        if (q >= 256u || pos >= limit) {   // the 256-ones escape (rice.rs:134-139): left to the serial reader
-            A.serial[ch] = 1;
-            return;
-        }
-        const uint32_t rem = k ? win(pos + 1u) >> (32u - k) : 0u;
-        const uint32_t u = (q << k) | rem;
-        out[idx++] = (int)(u >> 1) ^ -(int)(u & 1u);
-        pos += 1u + k;
-    }
+    if (escape) A.serial[ch] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------ 4. predictors
