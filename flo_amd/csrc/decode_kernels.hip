@@ -20,11 +20,11 @@ __device__ __forceinline__ uint32_t rd_u32(const uint8_t *p) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
-// One wavefront decodes a run of kDecRun consecutive output blocks of one clip: output block b (1024 sample-frames) is
+// One wavefront decodes a run of D.run (8 or 16) consecutive output blocks of one clip: output block b (1024 sample-frames) is
 // the first half of frame b + 1 plus the second half of frame b (mdct.rs:449-456; the first frame's own block is
-// dropped, lib.rs:338-341), so the run needs kDecRun + 1 frames and keeps the previous frame's second half in LDS.
+// dropped, lib.rs:338-341), so the run needs one frame more than blocks and keeps the previous frame's second half in LDS.
 // Every output sample is written exactly once, by plain stores.
-constexpr int kDecRun = 8;
+constexpr int kDecRunShort = 8, kDecRunLong = 16;   // output blocks per wavefront: short runs when there is little to decode
 constexpr int kBlobStage = 2304;
 
 __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
@@ -45,9 +45,10 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
     const unsigned clip = blockIdx.x;   // clips in x: gridDim.y stops at 65535
     if (clip >= (unsigned)D.n_clips) return;
     const unsigned nframes = D.clip_frames[clip];
-    const unsigned h0 = blockIdx.y * kDecRun;          // first frame of the run = first output block
+    const unsigned run = (unsigned)D.run;
+    const unsigned h0 = blockIdx.y * run;              // first frame of the run = first output block
     if (nframes < 2 || h0 + 1 >= nframes) return;
-    const unsigned h1 = h0 + kDecRun < nframes - 1 ? h0 + kDecRun : nframes - 1;   // last frame of the run
+    const unsigned h1 = h0 + run < nframes - 1 ? h0 + run : nframes - 1;   // last frame of the run
     float *out = D.out + D.clip_out[clip];
     const float scale = 2.0f / 1024.0f;
     const float *win = D.window;
@@ -458,9 +459,13 @@ __global__ __launch_bounds__(256) void ll_finish_kernel(LlFinishArgs A) {
         if (e_ != hipSuccess) return (int)e_;   \
     } while (0)
 
-int launch_lossy_decode(const LossyDecArgs &A, unsigned max_frames, hipStream_t s) {
-    if (max_frames < 2 || !A.n_clips) return 0;
-    const unsigned runs = (max_frames - 1 + kDecRun - 1) / kDecRun;
+int launch_lossy_decode(const LossyDecArgs &A0, unsigned max_frames, hipStream_t s) {
+    if (max_frames < 2 || !A0.n_clips) return 0;
+    LossyDecArgs A = A0;
+    // a run of R blocks decodes R + 1 frames: long runs waste less, short ones give a single file enough wavefronts
+    const unsigned long long blocks = (unsigned long long)A.n_clips * (max_frames - 1);
+    A.run = blocks >= 8ull * 4096ull ? kDecRunLong : kDecRunShort;
+    const unsigned runs = (max_frames - 1 + (unsigned)A.run - 1) / (unsigned)A.run;
     hipLaunchKernelGGL(lossy_decode_kernel, dim3((unsigned)A.n_clips, runs), dim3(64), 0, s, A);
     FLO_LAUNCH_CHECK();
     return 0;

@@ -21,6 +21,7 @@ struct LossyDecArgs {
     int channels;                     // header channel count (output interleave)
     float *out;                       // zero-filled: (frames - 1) * 1024 * channels floats per clip
     int *error;                       // set to 1 when a frame cannot be deserialised
+    int run;                          // output blocks per wavefront (set by the launcher)
 };
 
 // One ALPC / raw / silent channel wrapper of one frame = one thread.
