@@ -940,27 +940,26 @@ __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
             for (unsigned int i = threadIdx.x; i < nw; i += kLLThreads) stage[i] = 0u;
             __syncthreads();
             if (i0 < i1) {
-                unsigned long long pos = lead + rel_bit;
-                unsigned int word = (unsigned int)(pos >> 5), acc = 0;
-                int fill = (int)(pos & 31ull);
+                // The thread's bits go through a 64-bit shift register (bit 63 first): a code of at most 32 bits - unary
+                // part, terminator and remainder as ONE field for every quotient below 32 - k - is appended with one shift and
+                // one or, and the upper word leaves whenever it is complete. The first word a thread touches is shared with
+                // its predecessor and the last with its successor: those two are or-ed in, the ones between are stored.
+                const unsigned long long pos = lead + rel_bit;
+                unsigned int word = (unsigned int)(pos >> 5);
+                unsigned long long acc = 0;
+                int fill = (int)(pos & 31ull);   // bits of the word in front of this thread's first bit
                 bool first = true;
-                auto flush = [&](bool shared) {
-                    if (shared) { if (acc) atomicOr(&stage[word], acc); }
-                    else stage[word] = acc;
-                    word++;
-                    acc = 0;
-                    fill = 0;
-                    first = false;
-                };
-                auto put = [&](unsigned int value, int nbits) {   // nbits <= 32, value < 2^nbits, MSB-first
-                    while (nbits > 0) {
-                        const int room = 32 - fill;
-                        const int take = nbits < room ? nbits : room;
-                        const unsigned int part = (take == 32) ? value : ((value >> (nbits - take)) & ((1u << take) - 1u));
-                        acc |= (take == 32) ? part : (part << (room - take));
-                        fill += take;
-                        nbits -= take;
-                        if (fill == 32) flush(first);
+                auto put = [&](unsigned int value, int nbits) {   // 1 <= nbits <= 32, value < 2^nbits, fill < 32 on entry
+                    acc |= (unsigned long long)value << (64 - fill - nbits);
+                    fill += nbits;
+                    if (fill >= 32) {
+                        const unsigned int hi = (unsigned int)(acc >> 32);
+                        if (first) { if (hi) atomicOr(&stage[word], hi); }
+                        else stage[word] = hi;
+                        first = false;
+                        word++;
+                        acc <<= 32;
+                        fill -= 32;
                     }
                 };
 #pragma unroll
@@ -968,16 +967,24 @@ __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
                     if (i0 + j < i1) {
                         unsigned int q = u[j] >> k;
                         q = q < 255u ? q : 255u;
-                        unsigned int ones = q;
-                        while (ones >= 32) {
-                            put(0xFFFFFFFFu, 32);
-                            ones -= 32;
+                        const unsigned int rem = k ? (u[j] & ((1u << k) - 1u)) : 0u;
+                        if (q + 1u + (unsigned int)k <= 32u) {
+                            put(((((1u << q) - 1u) << 1) << k) | rem, (int)q + 1 + k);
+                        } else {
+                            unsigned int ones = q;
+                            while (ones >= 32) {
+                                put(0xFFFFFFFFu, 32);
+                                ones -= 32;
+                            }
+                            put(ones ? (((1u << ones) - 1u) << 1) : 0u, (int)ones + 1);
+                            if (k) put(rem, k);
                         }
-                        if (ones + 1 <= 32) put(ones ? (((1u << ones) - 1u) << 1) : 0u, (int)ones + 1);
-                        if (k) put(u[j] & ((1u << k) - 1u), k);
                     }
                 }
-                if (fill > 0) flush(true);
+                if (fill > 0) {
+                    const unsigned int hi = (unsigned int)(acc >> 32);
+                    if (hi) atomicOr(&stage[word], hi);
+                }
             }
             __syncthreads();
             unsigned int *gw = reinterpret_cast<unsigned int *>(base4) + (tile_abs >> 5);
