@@ -915,17 +915,27 @@ __global__ __launch_bounds__(kLLThreads) void ll_pack_kernel(LLArgs A) {
             }
 #undef FLO_RUN_CODES
         }
-        __syncthreads();   // the previous tile's readers of sc are done
-        sc[threadIdx.x] = bits;
-        __syncthreads();
-        for (int d = 1; d < kLLThreads; d <<= 1) {   // inclusive scan (Hillis-Steele over 256 entries)
-            unsigned long long t = threadIdx.x >= (unsigned int)d ? sc[threadIdx.x - d] : 0;
-            __syncthreads();
-            sc[threadIdx.x] += t;
-            __syncthreads();
+        // exclusive scan of the threads' bit counts inside the tile: in the wave by shuffles (a run is at most
+        // 16 x 271 bits, a tile below 2^21: 32 bits are plenty), across the four waves through LDS - two barriers per tile
+        // where the 256-entry Hillis-Steele scan took sixteen
+        unsigned int inc = bits;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int o = __shfl_up(inc, d, 64);
+            if ((int)(threadIdx.x & 63u) >= d) inc += o;
         }
-        const unsigned long long tile_total = sc[kLLThreads - 1];
-        const unsigned long long rel_bit = sc[threadIdx.x] - bits;            // inside the tile
+        __syncthreads();   // the previous tile's readers of sc are done
+        if ((threadIdx.x & 63u) == 63u) sc[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        unsigned int wave_base = 0, total32 = 0;
+#pragma unroll
+        for (int wv = 0; wv < kLLThreads / 64; wv++) {
+            const unsigned int t = (unsigned int)sc[wv];
+            if (wv < (int)(threadIdx.x >> 6)) wave_base += t;
+            total32 += t;
+        }
+        const unsigned long long tile_total = total32;
+        const unsigned long long rel_bit = (unsigned long long)(wave_base + inc) - bits;   // inside the tile
         const unsigned long long tile_abs = bit0 + tile_bit;                   // absolute bit position of the tile
         tile_bit += tile_total;
         // The tile's bits are composed in LDS and leave as whole words: only the first and the last word of a tile can
