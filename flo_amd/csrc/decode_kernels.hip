@@ -10,6 +10,8 @@
 // clip, parallel over a batch.
 #include "decode_kernels.hpp"
 
+#include <type_traits>
+
 namespace flo {
 
 // ------------------------------------------------------------------------------------------------ transform frames
@@ -40,7 +42,11 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
     __shared__ uint32_t rec[kMaxRecords];       // output index | count << 10 | byte position of the first value << 18
     __shared__ float sf[32];
     __shared__ int s_nrec;
-    __shared__ __attribute__((aligned(16))) uint8_t sblob[kBlobStage + 16];   // the channel's sparse bytes, staged
+    // the frame's bytes, staged whole (header, scale words, both channels' blobs: ~0.5 KB, 2.2 KB at most for what the
+    // encoder makes); a frame that does not fit is parsed in global memory and only its blob comes here
+    __shared__ __attribute__((aligned(16))) uint8_t sblob[kBlobStage + 16];
+    __shared__ unsigned long long s_foff[kDecRunLong + 1];
+    __shared__ uint32_t s_flen[kDecRunLong + 1];
     const int lane = (int)threadIdx.x;
     const unsigned clip = blockIdx.x;   // clips in x: gridDim.y stops at 65535
     if (clip >= (unsigned)D.n_clips) return;
@@ -53,16 +59,36 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
     const float scale = 2.0f / 1024.0f;
     const float *win = D.window;
 
-    for (uint32_t c = 0; c < (uint32_t)D.channels; c++) {
-        for (int j = lane; j < 1024; j += 64) prev[j] = 0.0f;
-        for (unsigned h = h0; h <= h1; h++) {
-            const unsigned long long f = D.clip_frame0[clip] + h;
-            const uint8_t *data = D.bytes + D.blob_off[f];
-            const uint32_t len = D.blob_len[f];
+    // where the run's frames are: one load per lane instead of one dependent load per frame
+    if ((unsigned)lane <= h1 - h0) {
+        const unsigned long long f = D.clip_frame0[clip] + h0 + (unsigned)lane;
+        s_foff[lane] = D.blob_off[f];
+        s_flen[lane] = D.blob_len[f];
+    }
+    __syncthreads();
+    // A frame travels global memory -> registers -> LDS, and the registers are filled one frame ahead: the walk over a
+    // frame used to start with three dependent global round trips (offset, channel length, blob), which was most of
+    // what a wave spent its time on.
+    constexpr int kPre = (kBlobStage + 255) / 256;   // dwords per lane
+    uint32_t pre[kPre];
+    auto fetch = [&](unsigned h) {
+        const uint8_t *g = D.bytes + s_foff[h - h0];
+        const uint32_t len = s_flen[h - h0];
+#pragma unroll
+        for (int j = 0; j < kPre; j++) {
+            const uint32_t i = 4u * ((uint32_t)lane + 64u * (uint32_t)j);
+            uint32_t w4 = 0;
+            if (len <= (uint32_t)kBlobStage && i < len) __builtin_memcpy(&w4, g + i, 4);   // up to 3 bytes past the frame: inside the file + slack
+            pre[j] = w4;
+        }
+    };
+    auto frame_ch = [&](const uint32_t c, const unsigned h, const uint8_t *data, const uint32_t len, auto IN_LDS) -> bool {
+        constexpr bool in_lds = decltype(IN_LDS)::value;
+        {
             // deserialize_frame: [block_size][channels][25 x u16 per channel][per channel: u32 len, sparse bytes]
             if (len < 2 || data[0] != 0 /* only Long blocks are produced or accepted */ || data[1] > D.channels) {
                 if (lane == 0) atomicExch(D.error, 1);
-                return;
+                return false;
             }
             const uint32_t nch = data[1];
             uint32_t pos = 2 + 50 * nch;
@@ -83,14 +109,15 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
             }
             if (bad) {
                 if (lane == 0) atomicExch(D.error, 1);
-                return;
+                return false;
             }
             const bool present = c < nch;      // a frame with fewer channels leaves the others silent
             if (present) {
                 // the record walk below is a chain of dependent byte reads: from LDS it costs a tenth of what it
                 // costs from global memory. Valid blobs are at most ~2.1 KB; anything longer is walked in place.
                 const uint8_t *sp = data + pos;
-                if (blen <= (uint32_t)kBlobStage) {
+                bool sp_lds = in_lds;
+                if (!in_lds && blen <= (uint32_t)kBlobStage) {
                     for (uint32_t i = 4u * lane; i < blen; i += 256u) {
                         uint32_t w4;
                         __builtin_memcpy(&w4, sp + i, 4);   // up to 3 bytes past the blob: inside the file + slack
@@ -98,6 +125,7 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
                     }
                     __syncthreads();
                     sp = sblob;
+                    sp_lds = true;
                 }
                 // scale factors: 2^((word - 32768) / 256), 0 when the word is 0 (decoder.rs:91-99)
                 if (lane < 25) {
@@ -110,7 +138,7 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
                 // positions (varint, count, length) into a table, and the chain walk is then ONE dependent LDS read per
                 // record instead of three to five byte reads. The table borrows `recon`, which is idle until the inverse
                 // transform; blobs beyond its 2048 entries (or walked in place) keep the byte-wise walk.
-                const bool tabled = sp == sblob && blen <= 2048u;
+                const bool tabled = sp_lds && blen <= 2048u;
                 uint32_t *ptab = reinterpret_cast<uint32_t *>(recon);
                 if (tabled) {
                     for (uint32_t p0 = (uint32_t)lane; p0 < blen; p0 += 64u) {
@@ -251,6 +279,30 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
             if (present)
                 for (int j = lane; j < 1024; j += 64) prev[j] = recon[1024 + j];
             __syncthreads();
+        }
+        return true;
+    };
+
+    for (uint32_t c = 0; c < (uint32_t)D.channels; c++) {
+        for (int j = lane; j < 1024; j += 64) prev[j] = 0.0f;
+        fetch(h0);
+        for (unsigned h = h0; h <= h1; h++) {
+            const uint32_t len = s_flen[h - h0];
+            bool ok;
+            if (len <= (uint32_t)kBlobStage) {
+#pragma unroll
+                for (int j = 0; j < kPre; j++) {
+                    const uint32_t i = 4u * ((uint32_t)lane + 64u * (uint32_t)j);
+                    if (i < len) *reinterpret_cast<uint32_t *>(sblob + i) = pre[j];
+                }
+                __syncthreads();
+                if (h < h1) fetch(h + 1);
+                ok = frame_ch(c, h, sblob, len, std::true_type{});
+            } else {
+                if (h < h1) fetch(h + 1);
+                ok = frame_ch(c, h, D.bytes + s_foff[h - h0], len, std::false_type{});
+            }
+            if (!ok) return;
         }
     }
 }
