@@ -353,8 +353,8 @@ def main():
                                             "hbm_algorithmic_GBs": round((4.0 * lsamples + lbytes) / d4 / 1e9, 1),
                                             "frac_of_hbm_peak": round((4.0 * lsamples + lbytes) / d4 / 1e9 / HBM_PEAK_GBS, 4)}}
         # decode of the same batch from its files in HBM into device memory (flo_batch_decode): the parallel Rice
-        # stages + the transposed f64 LPC recurrence (lldec_kernels.hip); wall time includes reading the compressed
-        # files back once for their headers and the host-side parse
+        # stages + the transposed f64 LPC recurrence (lldec_kernels.hip); the wrapper descriptions come from the
+        # encoder's own records (one small read-back), nothing is parsed
         import torch
         dst = torch.empty(lsamples, dtype=torch.float32, device=f"cuda:{local_rank}")
         torch.cuda.synchronize()

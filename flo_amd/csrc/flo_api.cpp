@@ -1425,43 +1425,65 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
     return FLO_OK;
 }
 
-// Lossless batches: the finished files stay where the encoder left them in HBM. What the host needs of them are the
-// headers (frame sizes, wrapper parameters), so the files are read back once for parsing - compressed bytes, one
-// pinned transfer - and every wrapper of every clip is decoded in one set of launches.
+// Lossless batches: the finished files stay where the encoder left them in HBM, and what a reader would find in them
+// is known from the encoder's own frame and channel records (lossless_describe): nothing is read back or parsed, every
+// wrapper of every clip is decoded in one set of launches.
 static int batch_decode_lossless(flo_batch *b, float *dst, size_t dst_cap, uint64_t *offsets) {
     flo_ctx *c = b->ctx;
-    const uint8_t *base;
-    const uint64_t *offs, *sizes;
-    if (lossless_device_files(b->ll, &base, &offs, &sizes) != 0) return fail(c, FLO_ERR_STATE, "batch has no finished files");
-    uint64_t lo = ~0ull, hi = 0;
-    for (size_t i = 0; i < b->n_clips; i++) {
-        if (offs[i] < lo) lo = offs[i];
-        if (offs[i] + sizes[i] > hi) hi = offs[i] + sizes[i];
-    }
-    if (!b->n_clips || hi <= lo) return FLO_OK;
-    int rc = ctx_stager(c);
-    if (rc != FLO_OK) return rc;
+    std::vector<LosslessFrameInfo> fr;
+    std::vector<LosslessWrapperInfo> wr;
+    const uint8_t *base = nullptr;
     std::string err;
-    uint8_t *host = (uint8_t *)stager_pinned_get(c->stager, hi - lo, err);
-    if (!host) return fail(c, FLO_ERR_NOMEM, err);
-    auto done = [&](int r) {
-        stager_pinned_put(c->stager, host);
-        return r;
-    };
-    if (hipMemcpyAsync(host, base + lo, hi - lo, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess)
-        return done(fail(c, FLO_ERR_DEVICE, "reading the batch's files back for parsing failed"));
+    if (lossless_describe(b->ll, fr, wr, &base, err) != 0) return fail(c, FLO_ERR_STATE, err);
     LlWork w;
-    for (size_t i = 0; i < b->n_clips; i++) {
-        ParsedFile f;
-        const char *perr = "";
-        if (parse_file(host + (offs[i] - lo), sizes[i], f, &perr) != 0) return done(fail(c, FLO_ERR_FORMAT, perr));
-        offsets[i] = w.out_sf * b->ch;
-        w.add(f, offs[i], b->ch);
+    w.chs.reserve(wr.size());
+    w.frs.reserve(fr.size());
+    for (size_t i = 0; i < b->n_clips; i++) offsets[i] = 0;
+    uint32_t cur = 0xFFFFFFFFu;
+    for (const LosslessFrameInfo &f : fr) {
+        if (f.clip != cur) {   // frames are in clip order: a clip's PCM starts where its first frame's does
+            cur = f.clip;
+            if (cur < b->n_clips) offsets[cur] = w.out_sf * b->ch;
+        }
+        LlFrameDev fd{};
+        fd.out_off = w.out_sf;
+        fd.first_channel = (unsigned)w.chs.size();
+        fd.n_channels = f.n_wrappers;
+        fd.samples = f.samples;
+        fd.mid_side = (b->ch == 2 && (f.flags & 1)) ? 1u : 0u;
+        for (uint32_t k = 0; k < f.n_wrappers; k++) {
+            const LosslessWrapperInfo &x = wr[f.first_wrapper + k];
+            LlChannelDev d{};
+            d.off = x.off;
+            d.out_off = w.scratch;
+            d.len = x.len;
+            d.samples = f.samples;
+            d.n_coeffs = x.n_coeffs;
+            d.shift_bits = x.shift_bits;
+            d.rice_k = x.rice_k;
+            memcpy(d.coeffs, x.coeffs, sizeof d.coeffs);
+            if (k < 2) fd.scratch_off[k] = w.scratch;
+            w.scratch += f.samples;
+            w.chs.push_back(d);
+        }
+        w.out_sf += f.samples;
+        if (f.samples > w.max_samples) w.max_samples = f.samples;
+        w.frs.push_back(fd);
+    }
+    // clips without frames (empty input) keep the offset of whatever follows them
+    {
+        uint64_t next = w.out_sf * b->ch;
+        std::vector<char> has(b->n_clips, 0);
+        for (const LosslessFrameInfo &f : fr)
+            if (f.clip < b->n_clips) has[f.clip] = 1;
+        for (size_t i = b->n_clips; i-- > 0;) {
+            if (has[i]) next = offsets[i];
+            else offsets[i] = next;
+        }
     }
     const uint64_t total = w.out_sf * b->ch;
-    if (total > dst_cap) return done(fail(c, FLO_ERR_ARG, "destination too small for the decoded batch"));
-    return done(ll_decode_device(c, w, base, b->ch, dst, nullptr));
+    if (total > dst_cap) return fail(c, FLO_ERR_ARG, "destination too small for the decoded batch");
+    return ll_decode_device(c, w, base, b->ch, dst, nullptr);
 }
 
 // Decode every clip of an encoded batch from its device bitstreams (no host round trip of the payload).

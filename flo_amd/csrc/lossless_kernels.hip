@@ -1278,6 +1278,56 @@ int lossless_device_files(LosslessPlan *p, const uint8_t **base, const uint64_t 
     return 0;
 }
 
+int lossless_describe(LosslessPlan *p, std::vector<LosslessFrameInfo> &frames, std::vector<LosslessWrapperInfo> &wrappers,
+                      const uint8_t **base, std::string &err) {
+    frames.clear();
+    wrappers.clear();
+    *base = p->d_out;
+    if (p->h_fout.size() != p->frames.size()) {
+        err = "lossless_describe: the batch has not been collected";
+        return -1;
+    }
+    std::vector<LLChan> chans(p->n_chans);
+    if (p->n_chans) {
+        hipError_t e = hipMemcpy(chans.data(), p->d_chans, p->n_chans * sizeof(LLChan), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            err = hipGetErrorString(e);
+            return -1;
+        }
+    }
+    frames.reserve(p->frames.size());
+    wrappers.reserve(p->n_chans);
+    for (size_t f = 0; f < p->frames.size(); f++) {
+        const LLFrame &fr = p->frames[f];
+        const LLFrameOut &fo = p->h_fout[f];
+        LosslessFrameInfo fi{fr.clip, fr.frame_samples, fo.flags, (uint32_t)wrappers.size(), (uint32_t)p->ch};
+        for (int c = 0; c < p->ch; c++) {
+            const LLChan &ch = chans[fr.first_chan + c];
+            LosslessWrapperInfo w{};
+            const uint64_t payload = p->clip_out_off[fr.clip] + ch.payload_off + 4;   // behind the u32 size
+            if (fo.frame_type == 0u) {                 // Silence: nothing to read
+                w.off = payload;
+            } else if (fo.frame_type == 254u) {        // Raw: at most frame_samples i16 (reader.rs raw branch)
+                const uint64_t need = 2ull * fr.frame_samples;
+                w.off = payload;
+                w.len = (uint32_t)(need < ch.payload_size ? need : ch.payload_size);
+            } else {                                   // ALPC wrapper: [order][coefficients][shift][encoding][k?][residuals]
+                const int ncoef = ch.kind == 2 ? ch.order : 0;
+                const uint32_t head = 1u + 4u * (uint32_t)ncoef + 1u + 1u + (ch.kind == 0 ? 0u : 1u);
+                w.n_coeffs = (uint8_t)ncoef;
+                for (int q = 0; q < ncoef && q < 12; q++) w.coeffs[q] = ch.coefs[q];
+                w.shift_bits = (uint8_t)(ch.kind == 1 ? 128 + ch.order : (ch.kind == 2 ? ch.shift : 0));
+                w.rice_k = (uint8_t)(ch.kind == 0 ? 0 : ch.k);   // encoding byte 2 (raw) carries no parameter
+                w.off = payload + head;
+                w.len = ch.payload_size > head ? ch.payload_size - head : 0u;
+            }
+            wrappers.push_back(w);
+        }
+        frames.push_back(fi);
+    }
+    return 0;
+}
+
 int lossless_fetch(LosslessPlan *p, size_t clip, uint8_t bit_depth, const uint8_t *meta, size_t meta_len, uint8_t **out,
                    size_t *out_len, std::string &err) {
     // the file was finished on the device: copy it, append META, patch bit_depth (header byte 13) and meta_size (62..69)

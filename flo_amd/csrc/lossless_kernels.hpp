@@ -22,6 +22,19 @@ int lossless_collect(LosslessPlan *p, std::string &err);
 uint64_t lossless_total_bytes(const LosslessPlan *p);
 int lossless_device_streams(LosslessPlan *p, const uint8_t **base, const uint64_t **offsets, const uint64_t **sizes);
 int lossless_device_files(LosslessPlan *p, const uint8_t **base, const uint64_t **offsets, const uint64_t **sizes);
+// What a reader of the finished files would find (reader.rs:150-256 applied to what ll_layout / ll_pack wrote), from
+// the encoder's own frame and channel records: the device decode of a batch needs no parse of its files.
+struct LosslessWrapperInfo {
+    uint64_t off;            // residual / raw payload, byte offset in the batch's output buffer
+    uint32_t len;
+    uint8_t n_coeffs, shift_bits, rice_k;
+    int32_t coeffs[12];
+};
+struct LosslessFrameInfo {
+    uint32_t clip, samples, flags, first_wrapper, n_wrappers;
+};
+int lossless_describe(LosslessPlan *p, std::vector<LosslessFrameInfo> &frames, std::vector<LosslessWrapperInfo> &wrappers,
+                      const uint8_t **base, std::string &err);
 int lossless_fetch(LosslessPlan *p, size_t clip, uint8_t bit_depth, const uint8_t *meta, size_t meta_len, uint8_t **out,
                    size_t *out_len, std::string &err);
 

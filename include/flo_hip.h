@@ -141,8 +141,8 @@ int flo_batch_pack_files(flo_batch *b, void *dst_device, size_t dst_cap, uint64_
 /* after sync: decode every clip from its device bitstream into dst (device memory, dst_cap floats). Clip i's PCM —
  * exactly what flo_decode returns for its file: (frames_i - 1) * 1024 * channels floats for a lossy clip, the
  * clip's interleaved samples for a lossless one — starts at offsets[i] floats (host array, n_clips entries). The
- * payload never leaves HBM (a lossless batch's files are read back once, compressed, for their headers):
- * full-size round-trip checks and the decode throughput figures. */
+ * payload never leaves HBM and nothing is parsed: frame and wrapper descriptions come from the batch's own encode
+ * records. Full-size round-trip checks and the decode throughput figures. */
 int flo_batch_decode(flo_batch *b, float *dst_device, size_t dst_cap_floats, uint64_t *offsets);
 
 /* ---- multi-GPU: one process per GPU, one exchange step per batch -------------------------

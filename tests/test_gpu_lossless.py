@@ -205,3 +205,42 @@ def test_full_size_batch_decodes_back_on_the_device(ctx, n_clips, seconds, sr):
     o_dec, _, _ = O.decode(b.fetch(0))
     assert np.array_equal(dec[0].cpu().numpy(), o_dec)
     b.close()
+
+
+@pytest.mark.parametrize("level", [0, 2, 5, 8])
+def test_batch_decode_equals_the_decode_of_each_fetched_file(ctx, level):
+    """flo_batch_decode builds its work from the encoder's own records instead of parsing the files: for every kind of
+    frame the encoder can emit (silence, raw, fixed, LPC, mid/side, a partial last frame, an empty clip, the level-0
+    quirk) the result must be, bit for bit, what flo_decode makes of the fetched file."""
+    import torch
+    import flo_amd
+    sr, ch = 44100, 2
+    rng = np.random.default_rng(level)
+    t = np.arange(sr) / sr
+    tone = (0.4 * np.sin(2 * np.pi * 330 * t)).astype(np.float32)
+    clips = [
+        np.zeros(0, np.float32),
+        np.zeros(sr * 2 * ch, np.float32),                                               # silence frames
+        rng.uniform(-1, 1, sr * ch + 2 * 777).astype(np.float32),                         # noise: raw wins; partial frame
+        np.stack([tone, tone * 0.98], 1).reshape(-1),                                    # mid/side
+        signals.music_like(sr, 3 * sr + 1234, ch, seed=level + 1),
+        np.concatenate([np.zeros(sr * ch, np.float32), signals.music_like(sr, 5000, ch, seed=9)]),
+        np.zeros(0, np.float32),
+    ]
+    b = flo_amd.Batch(ctx, flo_amd.MODE_LOSSLESS, [c.size for c in clips], sr, ch, level)
+    for i, c in enumerate(clips):
+        if c.size:
+            b.upload(i, c)
+    b.encode()
+    b.sync()
+    total = sum((c.size // ch) * ch for c in clips)
+    out = torch.full((total + 8,), 3.0, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    offs = b.decode_to(out.data_ptr(), out.numel())
+    host = out.cpu().numpy()
+    for i, c in enumerate(clips):
+        want = ctx.decode(b.fetch(i))
+        got = host[offs[i]:offs[i] + want.size]
+        assert np.array_equal(got, want), (level, i)
+    assert host[total] == 3.0       # nothing written behind the last clip
+    b.close()
