@@ -1,6 +1,8 @@
 // stager.cpp — see stager.hpp
 #include "stager.hpp"
 
+#include <cstdlib>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
@@ -170,7 +172,11 @@ int stager_upload(Stager *s, const std::vector<UploadSeg> &segs, hipStream_t str
     // a few megabytes: waking the copy threads costs more than they save; the runtime's own pageable path is used
     size_t total = 0;
     for (const UploadSeg &g : segs) total += g.bytes;
-    if (total <= kSmallUpload) {
+    static const size_t small_limit = [] {   // diagnostic override (MiB)
+        const char *e = getenv("FLO_SMALL_UPLOAD_MB");
+        return e ? (size_t)atoi(e) << 20 : kSmallUpload;
+    }();
+    if (total <= small_limit) {
         for (const UploadSeg &g : segs)
             if (g.bytes && hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, stream) != hipSuccess) {
                 err = "hipMemcpyAsync (upload) failed";
