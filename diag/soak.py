@@ -1,4 +1,4 @@
-"""Soak: the three-wave and two-wave chain kernels against the frame-parallel form, many times, several batch shapes."""
+"""Soak: the lock-step stereo, three-wave and two-wave chain kernels against the frame-parallel form, many times, several batch shapes."""
 import sys
 sys.path.insert(0, "/root/repo")
 import torch, flo_amd
@@ -17,7 +17,7 @@ for shape in ([sr * 10 * ch] * 1250, [sr * 3 * ch] * 2500, [(1000 + 977 * i) * c
         b.fill_synthetic(seed=1234, clip_id0=7)
         ref = packed(b, 2)
         for it in range(12):
-            for form in (3, 1):
+            for form in (4, 3, 1):
                 got = packed(b, form)
                 if got.shape != ref.shape or not torch.equal(got, ref):
                     bad += 1
