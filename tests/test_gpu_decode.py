@@ -261,3 +261,47 @@ def test_damaged_transform_payloads_decode_like_the_oracle_or_fail_like_it(ctx):
         assert np.max(np.abs(g[fin] - o[fin]), initial=0.0) <= 4e-6 * scale, pos
         same += 1
     assert errors > 5 and same > 50
+
+
+def test_random_damage_decodes_like_the_oracle_or_fails_like_it(ctx):
+    """A short differential fuzz (diag/dec_fuzz.py is the long one): random byte damage inside DATA of lossless and
+    lossy files. Whatever the oracle decoder makes of the file - an error, or PCM - the device decoder must make the
+    same: lossless integers exactly; lossy within 2e-6 of the file's own magnitude (a damaged scale word can blow a
+    frame up far beyond full scale)."""
+    rng = np.random.default_rng(2027)
+    pcm = signals.music_like(44100, 40000, 2, seed=4)
+    goods = [ctx.encode_lossless(pcm, 44100, 2, 16, 5), ctx.encode_lossless(pcm[:20001], 44100, 1, 16, 8),
+             ctx.encode_lossy(pcm, 44100, 2, 0.55), ctx.encode_lossy(pcm, 44100, 2, 1.0)]
+    rejected = 0
+    for it in range(80):
+        g = goods[it % len(goods)]
+        f = flofile.parse(g)
+        d0 = 70 + f.toc_size
+        b = bytearray(g)
+        for _ in range(int(rng.integers(1, 6))):
+            kind = int(rng.integers(0, 3))
+            at = int(rng.integers(d0, d0 + f.data_size))
+            if kind == 0:
+                b[at] = int(rng.integers(0, 256))
+            elif kind == 1:
+                b[at:at + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))
+            else:
+                b[at:at + 40] = b"\xff" * min(40, len(b) - at)
+        b = bytes(b)
+        try:
+            want = O.decode(b)[0]
+        except Exception:  # noqa: BLE001 - the oracle reports malformed input through exceptions
+            with pytest.raises(flo_amd.FloError):
+                ctx.decode(b)
+            rejected += 1
+            continue
+        got = ctx.decode(b)
+        assert got.shape == want.shape, it
+        if not want.size:
+            continue
+        with np.errstate(invalid="ignore", over="ignore"):
+            fin = np.isfinite(want) & np.isfinite(got)
+            assert np.array_equal(np.isnan(want), np.isnan(got)) and np.array_equal(np.isinf(want), np.isinf(got)), it
+            diff = np.abs(want[fin].astype(np.float64) - got[fin].astype(np.float64))
+            tol = 2e-6 * max(1.0, float(np.abs(want[fin]).max()) if fin.any() else 1.0) if f.is_lossy else 0.0
+        assert (float(diff.max()) if diff.size else 0.0) <= tol, (it, f.is_lossy)
