@@ -986,18 +986,29 @@ extern "C" int flo_encode_batch(flo_ctx *c, int mode, size_t n_clips, const floa
 static int encode_one(flo_ctx *c, int mode, const float *pcm, size_t n, uint32_t sr, uint8_t ch, float qol,
                       uint8_t bit_depth, const uint8_t *meta, size_t meta_len, uint8_t **out, size_t *out_len) {
     if (!c || !out || !out_len || (n && !pcm) || (meta_len && !meta)) return FLO_ERR_ARG;
+    static const bool trace = getenv("FLO_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = trace ? now() : 0;
     flo_batch *b = nullptr;
     int rc = flo_batch_create(c, mode, 1, &n, sr, ch, qol, &b);
     if (rc != FLO_OK) return rc;
     b->bit_depth = bit_depth;
+    const double t1 = trace ? now() : 0;
     {
         const float *one[1] = {pcm};
         rc = batch_upload_all(b, one);
     }
+    const double t2 = trace ? now() : 0;
     if (rc == FLO_OK) rc = flo_batch_encode(b, 0);
+    const double t3 = trace ? now() : 0;
     if (rc == FLO_OK) rc = flo_batch_sync(b);
+    const double t4 = trace ? now() : 0;
     if (rc == FLO_OK) rc = flo_batch_fetch(b, 0, meta, meta_len, out, out_len);
+    const double t5 = trace ? now() : 0;
     flo_batch_destroy(b);
+    if (trace)
+        fprintf(stderr, "[encode_one] create %.1f upload %.1f encode %.1f sync %.1f fetch %.1f destroy %.1f us\n", t1 - t0, t2 - t1,
+                t3 - t2, t4 - t3, t5 - t4, now() - t5);
     return rc;
 }
 
