@@ -489,3 +489,31 @@ def test_api_misuse_is_reported_not_crashed(ctx):
     with pytest.raises(flo_amd.FloError, match="too small"):
         lb.decode_to(small.data_ptr(), 1)               # lossless batches decode too; the capacity is checked alike
     lb.close()
+
+
+@pytest.mark.parametrize("amp", [1.0, 3000.0, 1e12])
+def test_kernel_forms_agree_on_loud_and_lopsided_stereo(ctx, amp):
+    """The lock-step forms put channel 1's bands on lanes 32..56 of the masking pass; far beyond full scale that pass
+    walks all 24 band distances (the rare branch of spread_threshold), and a silent or much quieter channel next to a
+    loud one is where a leak between the halves would show. Every form must give the same files."""
+    import flo_amd
+    sr, ch = 44100, 2
+    clips = []
+    for i in range(60):
+        x = signals.music_like(sr, 12000 + 37 * i, ch, seed=i) * amp
+        if i % 3 == 0:
+            x[1::2] *= 1e-3
+        if i % 5 == 0:
+            x[::2] = 0.0
+        clips.append(x.astype(np.float32))
+    outs = {}
+    for form in (4, 1, 2, 3):
+        b = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [c.size for c in clips], sr, ch, 0.55)
+        for i, c in enumerate(clips):
+            b.upload(i, c)
+        b.encode(form)
+        b.sync()
+        outs[form] = [b.fetch(i) for i in range(len(clips))]
+        b.close()
+    for form in (1, 2, 3):
+        assert outs[form] == outs[4], form
