@@ -51,7 +51,7 @@ struct LlParArgs {
     const uint8_t *bytes;
     const LlChannelDev *ch;
     unsigned int n_ch;
-    int *scratch;                     // zero-filled; residuals, then samples in place
+    int *scratch;                     // residuals, then samples in place (every wrapper's kernels write all of its samples)
     const unsigned int *tile0;        // [n_ch + 1]
     unsigned int *tabs;               // [tiles][kRiceStates]: exit state | codes started << 5, per entry state
     uint2 *tile_entry;                // [tiles]: (index of the first code that starts in the tile, entry state)

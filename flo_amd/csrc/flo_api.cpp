@@ -1290,9 +1290,13 @@ static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes,
     hipError_t e = pool_alloc(&d_scr.p, w.scratch ? w.scratch * sizeof(int) : 16);
     if (e == hipSuccess) e = pool_alloc(&d_tabs.p, tiles ? tiles * kRiceStates * sizeof(unsigned int) : 16);
     if (e == hipSuccess) e = pool_alloc(&d_ent.p, tiles ? tiles * sizeof(uint2) : 16);
-    if (e == hipSuccess && w.scratch) e = hipMemsetAsync(d_scr.p, 0, w.scratch * sizeof(int), c->stream);
-    if (e == hipSuccess && d_out) e = hipMemsetAsync(d_out, 0, n_out * sizeof(float), c->stream);
-    if (e == hipSuccess && d_out_i32) e = hipMemsetAsync(d_out_i32, 0, n_out * sizeof(int), c->stream);
+    // the output is cleared only when some frame carries fewer channels than the file (ll_finish writes every sample
+    // of every channel a frame has; the scratch needs no clearing: each wrapper's kernels write all of its samples)
+    bool partial = false;
+    for (const LlFrameDev &fd : w.frs)
+        if ((int)fd.n_channels < nch) partial = true;
+    if (e == hipSuccess && d_out && partial) e = hipMemsetAsync(d_out, 0, n_out * sizeof(float), c->stream);
+    if (e == hipSuccess && d_out_i32 && partial) e = hipMemsetAsync(d_out_i32, 0, n_out * sizeof(int), c->stream);
     if (e != hipSuccess) return fail(c, FLO_ERR_NOMEM, std::string("decode buffers: ") + hipGetErrorString(e));
     LlParArgs P{d_bytes, d_ch.as<LlChannelDev>(), (unsigned)w.chs.size(), d_scr.as<int>(),
                 d_t0.as<unsigned int>(), d_tabs.as<unsigned int>(), d_ent.as<uint2>(), d_ser.as<int>()};

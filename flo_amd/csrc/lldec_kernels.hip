@@ -26,7 +26,7 @@
 //                    Fixed predictors of order 1..4 are `order` wrapping prefix sums (decoder.rs:186-266 read as
 //                    difference equations, warm-up included); raw and silent wrappers are copies.
 // Zero padding stands in for the reader's end-of-stream rules: ones up to the end then a (virtual) 0, remainder bits
-// past the end read as 0, and a value that starts past the end is 0 (the scratch is zero-filled).
+// past the end read as 0, and a value that starts past the end is 0 (rice_chain clears those samples).
 #include "decode_kernels.hpp"
 
 namespace flo {
@@ -171,6 +171,14 @@ __global__ __launch_bounds__(64) void ll_rice_chain_kernel(LlParArgs A) {
         for (unsigned t = lane; t < m; t += 64) A.tile_entry[first + base + t] = ent[t];
         __syncthreads();
     }
+    // a value whose code would start behind the end of the stream is 0 (rice.rs:129-133): the scratch is not
+    // zero-filled beforehand, so the samples behind the last code that starts inside the stream are cleared here
+    {
+        const LlChannelDev c = A.ch[ch];
+        const uint32_t total = carry[1];
+        int *out = A.scratch + c.out_off;
+        for (uint32_t i = total + (uint32_t)lane; i < c.samples; i += 64u) out[i] = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ 3. residuals
@@ -279,17 +287,21 @@ __global__ __launch_bounds__(64) void ll_predict_kernel(LlParArgs A) {
         return;
     }
     if (!has_coeffs) {
-        if (has_res) {   // raw PCM: complete i16 pairs, the rest stays 0
-            const uint8_t *p = A.bytes + c.off;
-            const uint32_t pairs = c.len >> 1;
-            for (uint32_t i = lane; i < n && i < pairs; i += 64) r[i] = (int)(short)((uint32_t)p[2 * i] | ((uint32_t)p[2 * i + 1] << 8));
-        }
-        return;   // silence: the scratch is zero-filled
+        // raw PCM: complete i16 pairs, zeros behind them; silence: zeros
+        const uint8_t *p = A.bytes + c.off;
+        const uint32_t pairs = has_res ? c.len >> 1 : 0u;
+        for (uint32_t i = lane; i < n; i += 64)
+            r[i] = i < pairs ? (int)(short)((uint32_t)p[2 * i] | ((uint32_t)p[2 * i + 1] << 8)) : 0;
+        return;
     }
 
     // reconstruct_lpc_int
     const int order = c.n_coeffs;
-    if (n <= (uint32_t)order || !has_res) return;   // no residual bytes: every sample is 0
+    if (!has_res) {   // no residual bytes: every residual, hence every sample, is 0
+        for (uint32_t i = lane; i < n; i += 64) r[i] = 0;
+        return;
+    }
+    if (n <= (uint32_t)order) return;
     const uint32_t sh = c.shift_bits & 63u;
     cs[lane] = lane < order ? ldexp((double)c.coeffs[lane], -(int)sh) : 0.0;
     __syncthreads();
