@@ -19,7 +19,7 @@ struct LossyDecArgs {
     const unsigned long long *clip_out;     // [n_clips] float offset of the clip's PCM in `out`
     int n_clips;
     int channels;                     // header channel count (output interleave)
-    float *out;                       // zero-filled: (frames - 1) * 1024 * channels floats per clip
+    float *out;                       // (frames - 1) * 1024 * channels floats per clip, every one written
     int *error;                       // set to 1 when a frame cannot be deserialised
     int run;                          // output blocks per wavefront (set by the launcher)
 };

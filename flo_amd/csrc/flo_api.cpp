@@ -1372,7 +1372,7 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
                 return rc;
             }
             hipError_t e = pool_alloc(&d_out.p, n_out ? n_out * sizeof(float) : 16);
-            if (e == hipSuccess && n_out) e = hipMemsetAsync(d_out.p, 0, n_out * sizeof(float), c->stream);
+            // (no clearing: the decode kernel writes every sample of every output block exactly once)
             if (e != hipSuccess) {
                 free(host);
                 return fail(c, FLO_ERR_NOMEM, std::string("decode output: ") + hipGetErrorString(e));
@@ -1541,7 +1541,7 @@ extern "C" int flo_batch_decode(flo_batch *b, float *dst, size_t dst_cap, uint64
     if ((rc = upload(c, d_off, blob_off)) || (rc = upload(c, d_len, blob_len)) || (rc = upload(c, d_c0, c0)) ||
         (rc = upload(c, d_cn, cn)) || (rc = upload(c, d_co, co)) || (rc = upload(c, d_err, zero)))
         return rc;
-    HIPCHK(c, hipMemsetAsync(dst, 0, total * sizeof(float), c->stream));
+    // (dst needs no clearing: the decode kernel writes every sample of every output block exactly once)
     LossyDecArgs A{};
     A.T = b->ts->dev;
     A.window = b->ts->dev_window;
