@@ -33,7 +33,8 @@ namespace flo {
 
 namespace {
 constexpr int kTileWords = kRiceTileBits / 32;   // 64
-constexpr int kScanTiles = 4;                    // tiles per wavefront in rice_scan
+constexpr int kScanTiles = 4;                    // tiles per wavefront in rice_scan at k = 14 (16 entry states); 64 / (k + 2) in general
+constexpr int kScanTilesMax = 32;                // ... at k = 0
 constexpr int kScanStride = kTileWords + 2;      // a window read touches word w + 1
 constexpr int kDecOver = 16;                     // words past the last tile a code may reach (256 ones + k bits)
 constexpr int kChainChunk = 256;                 // tile tables staged per step of the chain walk
@@ -95,25 +96,28 @@ __device__ __forceinline__ bool is_rice(const LlChannelDev &c) {
 
 // ------------------------------------------------------------------------------------------------ 1. tile tables
 __global__ __launch_bounds__(64) void ll_rice_scan_kernel(LlParArgs A) {
-    __shared__ uint32_t words[kScanTiles * kScanStride];
+    __shared__ uint32_t words[kScanTilesMax * kScanStride];
     const unsigned ch = blockIdx.x;
     const unsigned nt = A.tile0[ch + 1] - A.tile0[ch];
-    const unsigned t0 = blockIdx.y * kScanTiles;
+    const LlChannelDev c = A.ch[ch];
+    const uint32_t k = c.rice_k;
+    // k + 2 lanes per tile (one per entry state), as many tiles as fit the wavefront. The grid is sized for four tiles
+    // per wavefront (k = 14): with a smaller k the surplus workgroups find nothing to do.
+    const uint32_t S = k + 2u, tpw = 64u / S;
+    const unsigned t0 = blockIdx.y * tpw;
     if (t0 >= nt) return;
     const int lane = (int)threadIdx.x;
-    const LlChannelDev c = A.ch[ch];
     const uint8_t *p = A.bytes + c.off;
-    // the four tiles are consecutive words of the stream: word i of the wave goes to tile i / 64 (the two spare words
-    // of a tile's row repeat the next tile's first two)
-    stage_words(p, c.len, t0 * kTileWords, kScanTiles * kTileWords + 2, lane, [&](int i, uint32_t v) {
+    // the tiles are consecutive words of the stream: word i of the wave goes to tile i / 64 (the two spare words of a
+    // tile's row repeat the next tile's first two)
+    stage_words(p, c.len, t0 * kTileWords, (int)(tpw * kTileWords + 2), lane, [&](int i, uint32_t v) {
         const int tile = i >> 6, w = i & 63;
-        if (tile < kScanTiles) words[tile * kScanStride + w] = v;
+        if (tile < (int)tpw) words[tile * kScanStride + w] = v;
         if (w < 2 && tile > 0) words[(tile - 1) * kScanStride + kTileWords + w] = v;
     });
     __syncthreads();
-    const uint32_t k = c.rice_k;
-    const uint32_t tile = (uint32_t)lane >> 4, st = (uint32_t)lane & 15u;
-    if (st > k + 1u || t0 + tile >= nt) return;
+    const uint32_t tile = (uint32_t)lane / S, st = (uint32_t)lane - tile * S;
+    if (tile >= tpw || t0 + tile >= nt) return;
     const uint32_t *w = words + tile * kScanStride;
     // One loop iteration per lane = one look at the 32 bits at `pos`, where the terminator of the current code (already
     // counted) is being searched: either the window is all ones (32 bits further, still inside the run) or it shows
