@@ -8,8 +8,8 @@
 // only thing a stretch of the stream needs to know about everything before it is *how it is entered*: in the middle
 // of a unary run, or with 0..k remainder bits still to skip. So
 //   1. rice_scan   : the stream is cut into tiles of 2048 bits; a lane walks one tile from one of the k + 2 possible
-//                    entry states (16 lanes per tile, 4 tiles per wavefront) and records where it leaves the tile and
-//                    how many codes started inside it;
+//                    entry states (k + 2 lanes per tile, 64 / (k + 2) tiles per wavefront) and records where it leaves
+//                    the tile and how many codes started inside it;
 //   2. rice_chain  : one wavefront per wrapper follows those tables from tile to tile (a few hundred dependent LDS
 //                    reads) and notes, per tile, the real entry state and the index of its first code;
 //   3. rice_decode : a lane per tile walks its tile once more from the now known entry and writes the residuals;
