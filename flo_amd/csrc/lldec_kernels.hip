@@ -351,8 +351,9 @@ __global__ __launch_bounds__(64) void ll_predict_kernel(LlParArgs A) {
         const double s = floor(outv);
         const uint32_t i = 64u * b + (uint32_t)lane;
         if (i < n) {
-            if (!(fabs(s) < 2147483648.0)) bad = true;
-            r[i] = (int)s;
+            const bool in_range = fabs(s) < 2147483648.0;   // (false for NaN too)
+            if (!in_range) bad = true;
+            r[i] = in_range ? (int)s : 0;   // a flagged wrapper is decoded again by the serial kernel
         }
     }
     if (bad) A.serial[chi] = 1;
