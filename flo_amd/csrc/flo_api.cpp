@@ -613,6 +613,9 @@ static int batch_encode_launch(flo_batch *b, int which) {
     int rc;
     if (which == 4 && b->exact) which = 3;
     if (which == 4 && b->ch == 2) {   // stereo: one lock-step transform wave + one packer wave per clip
+#ifdef FLO_STAMPS
+        if (!b->d_stamps) HIPCHK(c, pool_alloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
+#endif
         LossyArgs A = make_args(b);
         HIPCHK(c, hipMemsetAsync(b->d_next, 0, 4, c->stream));   // the batch-wide clip counter of the persistent workgroups
         rc = timed_launch(c, "lossy_chain2x", [&] { return launch_lossy_chain2x(A, c->stream); });
@@ -695,6 +698,19 @@ static int batch_sync_impl(flo_batch *b, hipEvent_t done) {
                 for (size_t w = 0; w < b->n_clips * b->ch; w++)
                     for (int i = 0; i < 14; i++) sum[i] += (double)st[w * 16 + i];
                 double frames = (double)b->total_frames * b->ch;
+                if (b->ch == 2 && (c->force_path == 4 || c->force_path == 0)) {   // lock-step form: wave 0 = transform, wave 1 = packer
+                    double t[14] = {0}, p[14] = {0};
+                    for (size_t k = 0; k < b->n_clips; k++)
+                        for (int i = 0; i < 14; i++) { t[i] += (double)st[(2 * k) * 16 + i]; p[i] += (double)st[(2 * k + 1) * 16 + i]; }
+                    static const char *tn[] = {"fold", "prefetch", "fft", "postrot", "bandstats", "mask", "quant", "wait-consumed", "handover"};
+                    static const char *pn[] = {"wait-ready", "read", "pack0", "pack1", "flush"};
+                    fprintf(stderr, "[stamps2x] ticks (10 ns) per stereo frame | T:");
+                    double tt = 0, pt = 0;
+                    for (int i = 0; i < 9; i++) { fprintf(stderr, " %s=%.1f", tn[i], t[i] / b->total_frames); tt += t[i]; }
+                    fprintf(stderr, " total=%.1f | P:", tt / b->total_frames);
+                    for (int i = 0; i < 5; i++) { fprintf(stderr, " %s=%.1f", pn[i], p[i] / b->total_frames); pt += p[i]; }
+                    fprintf(stderr, " total=%.1f\n", pt / b->total_frames);
+                }
                 static const char *nm[] = {"wait-loads+fold", "issue-loads", "fft", "postrot", "analyse(bands,psy,quant,plan)",
                                            "sync-tot", "emit", "sync-emit", "flush", "sync-tail"};
                 fprintf(stderr, "[stamps] s_memtime ticks (100 MHz) per frame-channel:");
@@ -1099,7 +1115,7 @@ extern "C" int flo_lossy_quantize(flo_ctx *c, const float *coeffs, size_t num_ho
 
 extern "C" int flo_sparse_pack(flo_ctx *c, const int16_t *q, size_t n_vec, int form, uint8_t *out, size_t out_cap,
                                uint32_t *out_off) {
-    if (!c || (n_vec && (!q || !out || !out_off)) || form < 0 || form > 1) return FLO_ERR_ARG;
+    if (!c || (n_vec && (!q || !out || !out_off)) || form < 0 || form > 2) return FLO_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (out_off) out_off[0] = 0;
     if (!n_vec) return FLO_OK;

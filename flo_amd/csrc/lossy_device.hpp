@@ -515,14 +515,20 @@ __device__ __forceinline__ void fft512_2(const int lane, v2f (&zr)[8], v2f (&zi)
 }
 
 // half-frame of a stereo clip as float2 loads: he[r] / ho[r] = (left, right) of the lane's even / odd sample of row r
+// Byte offsets (half_offsets x 8): rows r < 4 even 4096 + 16 lane + 1024 r, odd 4088 - 16 lane - 1024 r; rows r >= 4 even
+// 16 lane + 1024 (r - 4), odd 8184 - 16 lane - 1024 (r - 4). With va = 16 lane and vb = 16 (63 - lane) every load is
+// (uniform base or base + 4096) + (va or vb) + an instruction offset below 4096: two address registers, no arithmetic.
 __device__ __forceinline__ void load_half_fast_2(const int lane, const float *__restrict__ pcm, long long s0, v2f (&he)[8], v2f (&ho)[8]) {
-    const char *base = reinterpret_cast<const char *>(pcm + s0 * 2);
+    const char *base0 = reinterpret_cast<const char *>(pcm + s0 * 2);
+    const char *base1 = base0 + 4096;
+    const unsigned va = 16u * (unsigned)lane, vb = 16u * (unsigned)(63 - lane);
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        int eo, oo;
-        half_offsets(lane, r, eo, oo);
-        const float2 a = *reinterpret_cast<const float2 *>(base + (unsigned)eo * 8u);
-        const float2 b = *reinterpret_cast<const float2 *>(base + (unsigned)oo * 8u);
+        const int rr = r & 3;
+        const char *pe = (r < 4 ? base1 : base0) + va + 1024 * rr;
+        const char *po = (r < 4 ? base0 : base1) + vb + (3080 - 1024 * rr);
+        const float2 a = *reinterpret_cast<const float2 *>(pe);
+        const float2 b = *reinterpret_cast<const float2 *>(po);
         he[r] = (v2f){a.x, a.y};
         ho[r] = (v2f){b.x, b.y};
     }
@@ -552,17 +558,19 @@ __device__ __forceinline__ void fold_2(const int lane, const v2f (&ae)[8], const
 // post-rotation + transposition; c2: kCoef2 float2 elements, coefficient k of both channels at element k + 2 (k >> 4)
 __device__ __forceinline__ void post_rotate_transpose_2(const int lane, const v2f (&zr)[8], const v2f (&zi)[8], float2 *c2,
                                                         v2f (&c)[16], const LossyDevTables &T) {
+    // element of coefficient 2 m (m = lane + 64 r): 2 lane + 2 (lane >> 3) + 144 r; of coefficient 1023 - 2 m: 1149 minus
+    // that. One address register per direction, the row term is an instruction offset.
+    const int pl = 2 * lane + 2 * (lane >> 3);
+    float2 *const w0 = c2 + pl;
+    float2 *const w1 = c2 + (1149 - 7 * 144) - pl;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const int m = lane + 64 * r;
         const float4 t4 = T.pack[(8 + (r >> 1)) * 64 + lane];
         const v2f wx = splat2((r & 1) ? t4.z : t4.x), wy = splat2((r & 1) ? t4.w : t4.y);
-        const int k0 = 2 * m, k1 = 1023 - 2 * m;
-        const int p0 = k0 + 2 * (k0 >> 4), p1 = k1 + 2 * (k1 >> 4);
         const v2f R = fma2(-zi[r], wy, -(zr[r] * wx));
         const v2f I = fma2(zi[r], wx, -(zr[r] * wy));
-        c2[p0] = make_float2(R.x, R.y);
-        c2[p1] = make_float2(I.x, I.y);
+        w0[144 * r] = make_float2(R.x, R.y);
+        w1[144 * (7 - r)] = make_float2(I.x, I.y);
     }
     wave_sync();
     const float4 *p = reinterpret_cast<const float4 *>(&c2[18 * lane]);
@@ -872,8 +880,7 @@ struct StereoLds {
         struct {
             float2 sum[kSlots];   // per lane segment: (sum c^2 left, right) | 64 trash slots | zero slot
             float2 mx[kSlots];    //                   (max |c| left, right)
-            float2 thr[32];       // per band: amplitude thresholds (left, right)
-            float2 sf[32];        // per band: scale factors
+            float4 ts[32];        // per band: amplitude thresholds (left, right), scale factors (left, right)
         } a;
     } u;
 };
@@ -941,41 +948,60 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
 }
 
 // quantise (shipped form: amplitude-domain keep test) for both channels, four coefficients at a time; the integers
-// leave as i16 pairs, element 2k in the low half of xs[ch][k] (the hand-over format of the packer wave)
+// leave as i16 pairs, element 2k in the low half of xs[ch][k] (the hand-over format of the packer wave).
+// Per coefficient and channel: sign-matched pred(0.5) by one bit-field insert, one truncating convert, the threshold
+// maximum, one compare and one select; the select of an odd element writes the upper half of the even element's
+// register directly (SDWA), so nothing is spent on packing. (threshold, scale) of a coefficient's band come from ONE
+// 16-byte gather. Same arithmetic as quantise<., false>: bit-identical integers.
 __device__ __forceinline__ void quantise_2(const int lane, const v2f (&c)[16], const StereoLds &L, const LossyDevTables &T,
                                            uint32_t (&xs)[2][8]) {
-    const char *thrb = reinterpret_cast<const char *>(L.u.a.thr), *sfb = reinterpret_cast<const char *>(L.u.a.sf);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4f lds_f4;
+    const uint32_t ts0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)L.u.a.ts);
+    const uint32_t sgn_mask = 0x7FFFFFFFu;
+    uint32_t phalf = 0x3EFFFFFFu, zero = 0u;
+    asm volatile("" : "+v"(phalf), "+v"(zero));   // kept in registers: VOP3 / SDWA operands cannot be literals
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const float4 al4 = T.pack[(20 + g) * 64 + lane];
         const float4 bo4 = T.pack[(27 + g) * 64 + lane];
         const float al[4] = {al4.x, al4.y, al4.z, al4.w};
         const uint32_t bo[4] = {__float_as_uint(bo4.x), __float_as_uint(bo4.y), __float_as_uint(bo4.z), __float_as_uint(bo4.w)};
-        float2 th[4], sf[4];
+        v4f tb[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            th[k] = *reinterpret_cast<const float2 *>(thrb + bo[k]);
-            sf[k] = *reinterpret_cast<const float2 *>(sfb + bo[k]);
-        }
+        for (int k = 0; k < 4; k++) tb[k] = *reinterpret_cast<const lds_f4 *>((uintptr_t)(ts0 + 2u * bo[k]));   // bo = 8 * band
         int v[2][4];
+        float t[2][4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const v2f x = c[4 * g + k];
-            const v2f xsc = x * (v2f){sf[k].x, sf[k].y};
-            const v2f half = {__uint_as_float((__float_as_uint(xsc.x) & 0x80000000u) | 0x3EFFFFFFu),
-                              __uint_as_float((__float_as_uint(xsc.y) & 0x80000000u) | 0x3EFFFFFFu)};
-            const v2f rs = xsc + half;
-            const float t0 = max_raw(th[k].x, al[k]), t1 = max_raw(th[k].y, al[k]);
-            // (compare + select instead of the sign mask was measured: 62 fewer vector, 188 more scalar instructions, 1.4 % slower)
-            const int m0 = __float_as_int(t0 - fabsf(x.x)) >> 31, m1 = __float_as_int(t1 - fabsf(x.y)) >> 31;
-            v[0][k] = cvt_rz(rs.x) & m0;
-            v[1][k] = cvt_rz(rs.y) & m1;
+            const v2f xsc = x * (v2f){tb[k].z, tb[k].w};
+            uint32_t h0, h1;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(h0) : "s"(sgn_mask), "v"(phalf), "v"(xsc.x));
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(h1) : "s"(sgn_mask), "v"(phalf), "v"(xsc.y));
+            const v2f rs = xsc + (v2f){__uint_as_float(h0), __uint_as_float(h1)};
+            v[0][k] = cvt_rz(rs.x);
+            v[1][k] = cvt_rz(rs.y);
+            t[0][k] = max_raw(tb[k].x, al[k]);
+            t[1][k] = max_raw(tb[k].y, al[k]);
         }
 #pragma unroll
-        for (int ch = 0; ch < 2; ch++) {
-            xs[ch][2 * g] = __builtin_amdgcn_perm((uint32_t)v[ch][1], (uint32_t)v[ch][0], 0x05040100u);
-            xs[ch][2 * g + 1] = __builtin_amdgcn_perm((uint32_t)v[ch][3], (uint32_t)v[ch][2], 0x05040100u);
-        }
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) {
+                const float xe = ch ? c[4 * g + 2 * k2].y : c[4 * g + 2 * k2].x;
+                const float xo = ch ? c[4 * g + 2 * k2 + 1].y : c[4 * g + 2 * k2 + 1].x;
+                uint32_t r;
+                // keep iff |c| > thr (a NaN coefficient compares false like the reference, and converted to 0 anyway)
+                asm("v_cmp_gt_f32_e64 vcc, |%1|, %2\n\t"
+                    "v_cndmask_b32_e32 %0, %3, %4, vcc\n\t"
+                    "v_cmp_gt_f32_e64 vcc, |%5|, %6\n\t"
+                    "v_cndmask_b32_sdwa %0, %3, %7, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                    : "=&v"(r)
+                    : "v"(xe), "v"(t[ch][2 * k2]), "v"(zero), "v"(v[ch][2 * k2]), "v"(xo), "v"(t[ch][2 * k2 + 1]), "v"(v[ch][2 * k2 + 1])
+                    : "vcc");
+                xs[ch][2 * g + k2] = r;
+            }
     }
 }
 
@@ -1288,6 +1314,159 @@ __device__ __forceinline__ uint32_t sparse_ballot_pack(const int lane, const uin
     if (too_long) return kSparseFallback;
     // closing record of a trailing zero run: [varint zeros][0]  (cz = zeros behind the last non-zero, 1024 if none)
     uint32_t tot = 2u * (N + R) + W;
+    if (cz != 0u) {
+        const uint32_t ta = blob + tot;
+        if (lane == 0) {
+            if (cz >= 128u) {
+                lds_st8_at(ta, (cz & 0x7Fu) | 0x80u, 0);
+                lds_st8_at(ta, cz >> 7, 1);
+                lds_st8_at(ta, 0u, 2);
+            } else {
+                lds_st8_at(ta, cz, 0);
+                lds_st8_at(ta, 0u, 1);
+            }
+        }
+        tot += cz >= 128u ? 3u : 2u;
+    }
+    return tot;
+}
+
+// ------------------------------------------------------------------------------------------------ sparse RLE, list form
+// serialize_sparse (encoder.rs:284-314) for sparse frames, item-stationary: what nearly every frame of a q <= 0.8
+// encode looks like is about 60 non-zeros in 20 runs spread over 7 of the 16 ballot words, so the work is done per
+// NON-ZERO instead of per word position.
+//   build   per non-empty word of the strided view (x[e] = value at position 64 e + lane): one compare gives the word's
+//           ballot, two v_mbcnt the rank of each non-zero, and the non-zero lanes append (position << 16 | value) to a
+//           list in LDS. The only scalar state carried from word to word is the count.
+//   emit    lane i takes list item i (64 at a time): its predecessor's position tells whether it starts a run and how
+//           long the zero run in front of it is; ballots of "starts" and of "starts behind 128 zeros or more" (two-byte
+//           varint) give, through v_mbcnt, the byte offset 2 (items + records so far) + (wide records so far). The lane
+//           stores its value, a start lane also its zero-run varint and a run-table entry (offset of its count byte,
+//           rank); then one lane per RUN takes the count as the difference of neighbouring ranks.
+// Not handled (the caller takes the general form, which rewrites the blob): more than kListCap non-zeros, more runs
+// than the run table holds, a run longer than 255 (continuation records). All of them are dense frames.
+// LDS scratch: tab = kRunTabEntries dwords; lst = kListCap dwords with TWO more dwords in front of it (lst - 8: the
+// inactive lanes' store target, lst - 4: the "position -1" sentinel).
+constexpr int kListCap = 256;
+
+__device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ void lds_st8_any(uint32_t a, uint32_t v) {
+    asm volatile("ds_write_b8 %0, %1" ::"v"(a), "v"(v));
+}
+__device__ __forceinline__ void lds_st8_any1(uint32_t a, uint32_t v) {
+    asm volatile("ds_write_b8 %0, %1 offset:1" ::"v"(a), "v"(v));
+}
+__device__ __forceinline__ void lds_st32_any(uint32_t a, uint32_t v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v));
+}
+
+struct SparseList {
+    uint32_t n;       // non-zeros (uniform); more than kListCap: the list is incomplete
+    uint32_t last;    // position of the last non-zero (valid when n > 0)
+};
+
+__device__ __forceinline__ SparseList sparse_list_build(const int lane, const uint32_t (&x)[16], const uint32_t lst) {
+    uint32_t n = 0, last_hi = 0;
+    unsigned long long last_b = 1ull;
+    const uint32_t lane16 = (uint32_t)lane << 16;
+    const uint32_t amax = lst + 4u * (uint32_t)(kListCap - 1);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        // four ballots at a time: one wait for the vector unit's masks per group, one branch for four empty words
+        unsigned long long b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) b[k] = __ballot(x[4 * g + k] != 0u);
+        if ((b[0] | b[1] | b[2] | b[3]) == 0ull) continue;   // uniform
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (b[k] == 0ull) continue;   // uniform
+            const int e = 4 * g + k;
+            uint32_t a = (mbcnt64(b[k]) << 2) + (lst + 4u * n);
+            a = a < amax ? a : amax;
+            const uint32_t ent = x[e] | lane16 | ((uint32_t)(64 * e) << 16);
+            unsigned long long sv;
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv)
+                         : "s"(b[k]), "v"(a), "v"(ent));
+            n += (uint32_t)__builtin_popcountll(b[k]);
+            last_hi = (uint32_t)(64 * e);
+            last_b = b[k];
+        }
+    }
+    SparseList L;
+    L.n = n;
+    L.last = last_hi + 63u - (uint32_t)__builtin_clzll(last_b);
+    return L;
+}
+
+// blob: LDS byte address of the channel's first sparse byte. Returns the blob's length, or kSparseFallback.
+__device__ __forceinline__ uint32_t sparse_list_emit(const int lane, const SparseList L, const uint32_t blob, const uint32_t tab,
+                                                     const uint32_t lst) {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t N = L.n;
+    if (N > (uint32_t)kListCap) return kSparseFallback;
+    if (N == 0u) {   // 1024 zeros: [varint 1024][0] = 80 08 00
+        if (lane == 0) {
+            lds_st8_at(blob, 0x80u, 0);
+            lds_st8_at(blob, 0x08u, 1);
+            lds_st8_at(blob, 0u, 2);
+        }
+        return 3u;
+    }
+    const uint32_t trash = lst - 8u;
+    if (lane == 0) lds_st32_any(lst - 4u, 0xFFFF0000u);
+    wave_sync();
+    uint32_t Rb = 0, Wb = 0;
+    const uint32_t tmax = tab + 4u * (uint32_t)(kRunTabEntries - 1);
+    for (uint32_t g0 = 0; g0 < N; g0 += 64u) {
+        const uint32_t g = g0 + (uint32_t)lane;
+        const bool act = g < N;
+        const uint32_t la = lst + 4u * (act ? g : 0u);
+        const uint32_t tprev = *reinterpret_cast<const lds_u32 *>((uintptr_t)(la - 4u));
+        const uint32_t ent = *reinterpret_cast<const lds_u32 *>((uintptr_t)la);
+        const int p = (int)(ent >> 16), pprev = (int)tprev >> 16;
+        const uint32_t zrun = (uint32_t)(p - pprev - 1);
+        const bool start = act && (zrun != 0u || g == 0u);
+        const bool wide = start && zrun >= 128u;
+        const unsigned long long SB = __ballot(start), WB = __ballot(wide);
+        const uint32_t r_excl = Rb + mbcnt64(SB);
+        uint32_t w_incl = Wb;
+        if (WB != 0ull) w_incl += mbcnt64(WB) + (wide ? 1u : 0u);   // uniform
+        const uint32_t off_v = ((g + r_excl + (start ? 1u : 0u)) << 1) + w_incl;   // relative to the blob
+        const uint32_t av = act ? blob + off_v : trash;
+        lds_st8_any(av, ent);
+        lds_st8_any1(av, ent >> 8);
+        // record header in front of a start lane's value: [varint zero_run][count]; the count byte is filled in below
+        const uint32_t ah = start ? blob + off_v - 2u - (wide ? 1u : 0u) : trash;
+        lds_st8_any(ah, wide ? ((zrun & 0x7Fu) | 0x80u) : zrun);
+        if (WB != 0ull) lds_st8_any1(wide ? ah : trash, zrun >> 7);   // uniform
+        uint32_t ta = tab + 4u * r_excl;
+        ta = ta < tmax ? ta : tmax;
+        lds_st32_any(start ? ta : trash, ((off_v - 1u) << 16) | g);
+        Rb += (uint32_t)__builtin_popcountll(SB);
+        Wb += (uint32_t)__builtin_popcountll(WB);
+    }
+    const uint32_t R = Rb, W = Wb;
+    if (R > (uint32_t)(kRunTabEntries - 1)) return kSparseFallback;
+    if (lane == 0) lds_st32_any(tab + 4u * R, N);   // sentinel: rank N
+    wave_sync();
+    bool too_long = false;
+    for (uint32_t j0 = 0; j0 < R; j0 += 64u) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        const bool act = j < R;
+        const uint32_t ja = tab + 4u * (act ? j : 0u);
+        const uint32_t t0 = *reinterpret_cast<const lds_u32 *>((uintptr_t)ja);
+        const uint32_t t1 = *reinterpret_cast<const lds_u32 *>((uintptr_t)(ja + 4u));
+        const uint32_t cnt = (t1 & 0xFFFFu) - (t0 & 0xFFFFu);
+        too_long |= __ballot(act && cnt > 255u) != 0ull;
+        lds_st8_any(act ? blob + (t0 >> 16) : trash, cnt);
+    }
+    if (too_long) return kSparseFallback;
+    // closing record of a trailing zero run: [varint zeros][0]
+    uint32_t tot = 2u * (N + R) + W;
+    const uint32_t cz = 1023u - L.last;
     if (cz != 0u) {
         const uint32_t ta = blob + tot;
         if (lane == 0) {

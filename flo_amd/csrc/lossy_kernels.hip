@@ -785,10 +785,16 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         unsigned long long written = 0;
         uint32_t pend = 0, tailb = 0;
         const uint32_t tab_a = (uint32_t)(uintptr_t)cs.runtab;
+        const uint32_t stage_a = (uint32_t)(uintptr_t)cs.stage;
+#ifdef FLO_STAMPS
+        unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
         for (unsigned h = 0; h < hops; h++) {
             const int ln = lane_id_opaque();
             wait_counter(&cs.ready[0], fbase + h + 1);
             wait_counter(&cs.ready[1], fbase + h + 1);
+            STAMP(0);
             // hand-over buffer of a channel: value 16 l + k sits at halfword 8 l + k (k < 8) or 512 + 8 l + k - 8.
             // Strided view for the ballot form: x[e] = value at position 64 e + lane.
             uint32_t x[2][16], xs[2][8];
@@ -805,6 +811,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             }
             const uint32_t sfw_both = cs.sfwh[ln >> 5][ln & 31];   // scale words: lanes 0..24 left, 32..56 right
             set_counter(&cs.consumed, fbase + h + 1);
+            STAMP(1);
 #if FLO_ABLATE3 >= 1
             for (int e = 0; e < 16; e++) { FLO_KEEP(x[0][e]); FLO_KEEP(x[1][e]); }
             for (int e = 0; e < 8; e++) { FLO_KEEP(xs[0][e]); FLO_KEEP(xs[1][e]); }
@@ -821,10 +828,16 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             }
             uint32_t tot[2];
             uint32_t pos = 112;   // 12 + 50 * 2: length word of channel 0
+            // the two channels' item lists live in the unused tail of the staging buffer (a frame that takes the list
+            // form is at most 1.7 KB long; the general form only runs when the lists are dead)
+            const uint32_t lst_a[2] = {stage_a + 2048u + 8u, stage_a + 3088u + 8u};
+            SparseList SL[2];
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) SL[ch] = sparse_list_build(ln, x[ch], lst_a[ch]);
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
-                uint32_t t = sparse_ballot_pack(ln, x[ch], f_a + pos + 4u, tab_a);
-                if (t == kSparseFallback) {   // uniform: dense frame (a run longer than 255, or more than 126 runs)
+                uint32_t t = sparse_list_emit(ln, SL[ch], f_a + pos + 4u, tab_a, lst_a[ch]);
+                if (t == kSparseFallback) {   // uniform: dense frame (many non-zeros or runs, a run longer than 255)
                     int q[1][16];
                     uint32_t hi[8];
 #pragma unroll
@@ -847,6 +860,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
                     p[0] = (uint8_t)t; p[1] = (uint8_t)(t >> 8); p[2] = (uint8_t)(t >> 16); p[3] = (uint8_t)(t >> 24);
                 }
                 pos += 4u + t;
+                STAMP(2 + ch);
             }
             const uint32_t flen = pos, blob_len = flen - 10;
             if (ln == 0) {
@@ -868,9 +882,14 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             tailb = (ln < (int)pend) ? stage[(n16 << 4) + ln] : 0u;
             written += (unsigned long long)n16 << 4;
             wave_sync();
+            STAMP(4);
         }
         if (lane < (int)pend) gout[written + lane] = (uint8_t)tailb;
         if (lane == 0) A.clip_bytes[clip] = written + pend;
+#ifdef FLO_STAMPS
+        if (A.dbg_stamps && lane == 0)
+            for (int i = 0; i < 14; i++) A.dbg_stamps[((unsigned long long)clip * 2 + 1) * 16 + i] = st_sum[i];
+#endif
         fbase += hops;
         continue;
     }
@@ -893,6 +912,10 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
 #else
 #define FLO_MARK(x)
 #endif
+#ifdef FLO_STAMPS
+    unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
     auto frame_body = [&](const unsigned h, v2f (&pe)[8], v2f (&po)[8], v2f (&ce)[8], v2f (&co)[8]) __attribute__((always_inline)) {
         const int ln = lane_id_opaque();
         FLO_MARK("frame_begin");
@@ -909,15 +932,19 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             v2f zr[8], zi[8];
             fold_2(ln, pe, po, ce, co, zr, zi, T);
             FLO_MARK("fold_done");
+            STAMP(0);
             // the older half is dead after the fold: the half-frame after next is loaded into its registers now and
             // consumed at the top of the next call. Unconditional, also behind the last frame (the batch allocates one
             // spare half-frame per clip): see lossy_chain_kernel
             load_half_fast_2(ln, pcm, (long long)(h + 1) * 1024, pe, po);
             FLO_MARK("prefetch_done");
+            STAMP(1);
             fft512_2(ln, zr, zi, lds.u.xch4, T);
             FLO_MARK("fft_done");
+            STAMP(2);
             post_rotate_transpose_2(ln, zr, zi, lds.u.coef2, c, T);
             FLO_MARK("postrot_done");
+            STAMP(3);
 
             if (A.dbg_coeffs) {
 #pragma unroll
@@ -932,6 +959,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         v2f energy, bmax;
         band_stats_2(ln, c, lds, T, energy, bmax);
         FLO_MARK("bandstats_done");
+        STAMP(4);
 #ifndef FLO_SPLIT_MASK
         // masking level, temporal step and scale factors of both channels in one pass: channel 0 on lanes 0..24, channel 1
         // on lanes 32..56 (band_stats_2 leaves every band's totals in both halves)
@@ -947,15 +975,17 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
             sfw1 = sf_word(sfv1);
             if (bnd < 25) {
-                reinterpret_cast<float *>(&lds.u.a.thr[bnd])[up] = tl1;
-                reinterpret_cast<float *>(&lds.u.a.sf[bnd])[up] = sfv1;
+                reinterpret_cast<float *>(&lds.u.a.ts[bnd])[up] = tl1;
+                reinterpret_cast<float *>(&lds.u.a.ts[bnd])[2 + up] = sfv1;
             }
         }
         wave_sync();
         FLO_MARK("mask_done");
+        STAMP(5);
         uint32_t xs[2][8];
         quantise_2(ln, c, lds, T, xs);
         FLO_MARK("quant_done");
+        STAMP(6);
         if (A.dbg_q) {
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
@@ -966,6 +996,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         }
         if (A.dbg_sfw && bnd < 25) A.dbg_sfw[((frame0 + h) * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
         wait_counter(&cs.consumed, fbase + h);   // the packer has taken the previous frame out of the hand-over buffer
+        STAMP(7);
 #pragma unroll
         for (int ch = 0; ch < 2; ch++) {
             uint4 *dq = reinterpret_cast<uint4 *>(cs.qh[ch]);
@@ -976,6 +1007,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         set_counter(&cs.ready[0], fbase + h + 1);
         set_counter(&cs.ready[1], fbase + h + 1);
         FLO_MARK("frame_end");
+        STAMP(8);
 #else
         const float rcount = T.pack[26 * 64 + ln].z;
         uint32_t sfw[2];
@@ -990,10 +1022,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             sfv[ch] = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
             sfw[ch] = sf_word(sfv[ch]);
         }
-        if (ln < 25) {
-            lds.u.a.thr[ln] = make_float2(tl[0], tl[1]);
-            lds.u.a.sf[ln] = make_float2(sfv[0], sfv[1]);
-        }
+        if (ln < 25) lds.u.a.ts[ln] = make_float4(tl[0], tl[1], sfv[0], sfv[1]);
         wave_sync();
         uint32_t xs[2][8];
         quantise_2(ln, c, lds, T, xs);
@@ -1025,6 +1054,10 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         frame_body(h, ae, ao, be, bo);
         if (h + 1 < hops) frame_body(h + 1, be, bo, ae, ao);
     }
+#ifdef FLO_STAMPS
+    if (A.dbg_stamps && lane == 0)
+        for (int i = 0; i < 14; i++) { A.dbg_stamps[((unsigned long long)clip * 2) * 16 + i] = st_sum[i]; st_sum[i] = 0; }
+#endif
     fbase += hops;
     }   // next clip
 }
@@ -1148,8 +1181,8 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
     const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
     const uint32_t sfw1 = sf_word(sfv1);
     if (bnd < 25) {
-        reinterpret_cast<float *>(&lds.u.a.thr[bnd])[up] = tl1;
-        reinterpret_cast<float *>(&lds.u.a.sf[bnd])[up] = sfv1;
+        reinterpret_cast<float *>(&lds.u.a.ts[bnd])[up] = tl1;
+        reinterpret_cast<float *>(&lds.u.a.ts[bnd])[2 + up] = sfv1;
     }
     wave_sync();
     uint32_t xs[2][8];
@@ -1413,12 +1446,13 @@ __global__ __launch_bounds__(64) void mdct_only_kernel(LossyDevTables T, const f
 }
 
 // serialize_sparse of independent 1024-value vectors into fixed slots (flo_sparse_pack): the packer wave's own
-// routine, i.e. the ballot form with the general form behind it for the vectors it declines. form = 1 forces the
-// general form for every vector (tests compare the two).
+// routine, i.e. the list form with the general form behind it for the vectors it declines. form = 1 forces the
+// general form for every vector, form = 2 takes the ballot form first (tests compare the three).
 __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigned long long n, uint8_t *slots,
                                                          uint32_t *sizes, int form) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[2080 + 128];
     __shared__ uint32_t runtab[kRunTabEntries];
+    __shared__ uint32_t lst[kListCap + 2];
     const unsigned long long w = blockIdx.x;
     if (w >= n) return;
     const int lane = lane_id();
@@ -1426,7 +1460,14 @@ __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigne
     uint32_t x[16];
 #pragma unroll
     for (int e = 0; e < 16; e++) x[e] = qv[64 * e + lane];
-    uint32_t total = form == 1 ? kSparseFallback : sparse_ballot_pack(lane, x, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab);
+    uint32_t total = kSparseFallback;
+    if (form == 0) {
+        const uint32_t lst_a = (uint32_t)(uintptr_t)lst + 8u;
+        const SparseList SL = sparse_list_build(lane, x, lst_a);
+        total = sparse_list_emit(lane, SL, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab, lst_a);
+    } else if (form == 2) {
+        total = sparse_ballot_pack(lane, x, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab);
+    }
     if (total == kSparseFallback) {
         int v[16];
 #pragma unroll

@@ -55,9 +55,9 @@ def _patterns():
     return np.array(pats)
 
 
-@pytest.mark.parametrize("form", [0, 1], ids=["encoder", "general"])
+@pytest.mark.parametrize("form", [0, 1, 2], ids=["encoder", "general", "ballot"])
 def test_sparse_pack_bit_exact(ctx, form):
-    # form 0 = the packer as every encode runs it (ballot form, the general form behind it for dense vectors)
+    # form 0 = the packer as every encode runs it (list form, the general form behind it for dense vectors)
     pats = _patterns()
     got = ctx.sparse_pack(pats, form)
     for i, p in enumerate(pats):
@@ -103,12 +103,22 @@ def test_sparse_pack_ballot_form_on_structured_vectors(ctx):
         for _ in range(40):
             keep = rng.uniform(size=1024) < dens * np.exp(-np.arange(1024) / rng.uniform(100, 900))   # low-pass like a spectrum
             pats.append((rng.integers(-32768, 32768, 1024) * keep).astype(np.int16))
+    # the list form's own limits: exactly 255 / 256 / 257 non-zeros, 127 / 128 runs, items whose runs straddle the
+    # 64-item passes, a two-byte varint in front of item 64 and 128
+    for n in (63, 64, 65, 127, 128, 129, 255, 256, 257):
+        a = np.zeros(1024, np.int16); a[:2 * n:2][:n] = 5; pats.append(a)                    # n runs of one
+        b = np.zeros(1024, np.int16); b[100:100 + n] = -9; b[900] = 1; pats.append(b)        # one run of n, a wide gap
+        c = np.zeros(1024, np.int16); c[np.arange(n) * 3 % 1024] = 7; pats.append(c)
+    for k in (64, 128, 192):
+        a = np.zeros(1024, np.int16); a[:k] = 3; a[k + 200:k + 203] = 4; pats.append(a)      # wide record starts item k
+        b = np.zeros(1024, np.int16); b[:k - 1] = 3; b[k + 200:k + 203] = 4; pats.append(b)
     pats = np.array(pats)
-    got0, got1 = ctx.sparse_pack(pats, 0), ctx.sparse_pack(pats, 1)
+    got0, got1, got2 = ctx.sparse_pack(pats, 0), ctx.sparse_pack(pats, 1), ctx.sparse_pack(pats, 2)
     for i, p in enumerate(pats):
         ref = O.serialize_sparse(p)
         assert got0[i] == ref, i
         assert got1[i] == ref, i
+        assert got2[i] == ref, i
 
 
 @pytest.mark.parametrize("exact", [False, True], ids=["shipped", "exact"])
