@@ -277,6 +277,7 @@ static int get_tables(flo_ctx *c, uint32_t sr, float quality, TableSet **out) {
     t->dev.band_slot0 = (const uint32_t *)P(i_bs);
     t->dev_window = (const float *)P(i_win);
     t->dev.max_band_slots = h.max_band_slots;
+    t->dev.dirty = h.dirty;
     t->dev.smr_thr = h.smr_threshold;
     t->dev.q_transparent = h.q_transparent;
     if (h.n_slots > kSlotCap || h.max_band_slots > 64) {   // (cannot happen: 64 lanes + 24 band edges, 64 lanes per band)

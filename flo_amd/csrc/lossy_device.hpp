@@ -46,6 +46,7 @@ struct LossyDevTables {
     const uint32_t *lane_slot0;  // [64]
     const uint32_t *band_slot0;  // [26]
     int max_band_slots;
+    uint32_t dirty;          // bit e: some lane closes a band segment at element e of its 16 (the others skip the slot store)
     float smr_thr;
     int q_transparent;
 };
@@ -886,19 +887,36 @@ struct StereoLds {
 };
 
 // band_stats for both channels: the sums are packed (one fused multiply-add per coefficient pair), the maxima are not
-// (there is no packed maximum). Same slots, same order of additions per channel as band_stats<CH>.
+// (there is no packed maximum). Same slots, same order of additions per channel as band_stats<CH>: bit-identical.
+// What differs is the schedule: the slot lists are fetched (and rebased) before the running sums, so that the gathers
+// follow the slot writes without a table round trip in between; element positions at which no lane of the table closes
+// a segment (T.dirty, a uniform bitmap) skip the store and the restart multiplication (x 1.0 for every lane); and the
+// two halves of a band meet through ONE swap per quantity that also sorts the channels: the result has channel 0's
+// band b on lane b and channel 1's on lane 32 + b, which is what the merged masking pass consumes.
+template <uint32_t DIRTY = 0xFFFFu>
 __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16], StereoLds &L, const LossyDevTables &T,
-                                             v2f &energy, v2f &bmax) {
+                                             float &energy1, float &bmax1) {
     // Slot addresses as 32-bit LDS offsets from ONE scalar base: as the sum of the clip's LDS base and the member offset
     // the compiler re-added both terms for every access (two vector adds per slot instead of one). The accesses go
     // through address-space-3 pointers so that they stay ds_* instructions.
     typedef __attribute__((address_space(3))) v2f lds_v2f;
     const uint32_t sum0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)L.u.a.sum);
     const uint32_t mxd = (uint32_t)(reinterpret_cast<char *>(L.u.a.mx) - reinterpret_cast<char *>(L.u.a.sum));
-    if (lane == 0) {   // the zero slot shares storage with the exchange buffer: written every frame
-        L.u.a.sum[kZeroSlot] = make_float2(0.f, 0.f);
-        L.u.a.mx[kZeroSlot] = make_float2(0.f, 0.f);
+    {   // the zero slot shares storage with the exchange buffer: written every frame (by every lane: no branch)
+        const uint32_t z = sum0 + 8u * (uint32_t)kZeroSlot;
+        *reinterpret_cast<lds_v2f *>((uintptr_t)z) = splat2(0.f);
+        *reinterpret_cast<lds_v2f *>((uintptr_t)(z + mxd)) = splat2(0.f);
     }
+    uint32_t so[12];
+#ifndef FLO_BS_LATE_LISTS
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const float4 lst = T.pack[(39 + g) * 64 + lane];
+        so[4 * g + 0] = sum0 + __float_as_uint(lst.x), so[4 * g + 1] = sum0 + __float_as_uint(lst.y);
+        so[4 * g + 2] = sum0 + __float_as_uint(lst.z), so[4 * g + 3] = sum0 + __float_as_uint(lst.w);
+    }
+#endif
+    const uint32_t dirty = DIRTY;   // compile-time: straight-line code
     v2f acc = splat2(0.f), mx = splat2(0.f);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -912,26 +930,34 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
             acc = fma2(c[e], c[e], acc);
             mx.x = max_abs_raw(mx.x, c[e].x);
             mx.y = max_abs_raw(mx.y, c[e].y);
-            const uint32_t a = sum0 + dv[k];
-            *reinterpret_cast<lds_v2f *>((uintptr_t)a) = acc;
-            *reinterpret_cast<lds_v2f *>((uintptr_t)(a + mxd)) = mx;
-            acc = acc * splat2(kp[k]);
-            mx = mx * splat2(kp[k]);
+            if ((dirty >> e) & 1u) {   // compile-time
+                const uint32_t a = sum0 + dv[k];
+                *reinterpret_cast<lds_v2f *>((uintptr_t)a) = acc;
+                *reinterpret_cast<lds_v2f *>((uintptr_t)(a + mxd)) = mx;
+                if (e < 15) {
+                    acc = acc * splat2(kp[k]);
+                    mx = mx * splat2(kp[k]);
+                }
+            }
         }
     }
+#ifdef FLO_BS_LATE_LISTS
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const float4 lst = T.pack[(39 + g) * 64 + lane];
+        so[4 * g + 0] = sum0 + __float_as_uint(lst.x), so[4 * g + 1] = sum0 + __float_as_uint(lst.y);
+        so[4 * g + 2] = sum0 + __float_as_uint(lst.z), so[4 * g + 3] = sum0 + __float_as_uint(lst.w);
+    }
+#endif
     wave_sync();
-    energy = splat2(0.f);
-    bmax = splat2(0.f);
-    const int groups = (T.max_band_slots + 7) >> 3;
-    for (int g = 0; g < (groups < 3 ? 3 : groups); g++) {
-        const float4 lst = g < 6 ? T.pack[(39 + g) * 64 + lane] : T.pack_ext[(g - 6) * 64 + lane];
-        const uint32_t so[4] = {__float_as_uint(lst.x), __float_as_uint(lst.y), __float_as_uint(lst.z), __float_as_uint(lst.w)};
+    v2f energy = splat2(0.f), bmax = splat2(0.f);
+#pragma unroll
+    for (int g = 0; g < 3; g++) {   // four slots in flight at a time: twelve would not fit the register budget
         v2f vs[4], vm[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t a = sum0 + so[u];
-            vs[u] = *reinterpret_cast<const lds_v2f *>((uintptr_t)a);
-            vm[u] = *reinterpret_cast<const lds_v2f *>((uintptr_t)(a + mxd));
+            vs[u] = *reinterpret_cast<const lds_v2f *>((uintptr_t)so[4 * g + u]);
+            vm[u] = *reinterpret_cast<const lds_v2f *>((uintptr_t)(so[4 * g + u] + mxd));
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -940,10 +966,32 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
             bmax.y = max_raw(bmax.y, vm[u].y);
         }
     }
-    energy.x += from_other_half(energy.x);
-    energy.y += from_other_half(energy.y);
-    bmax.x = max_raw(bmax.x, from_other_half(bmax.x));
-    bmax.y = max_raw(bmax.y, from_other_half(bmax.y));
+    const int groups = (T.max_band_slots + 7) >> 3;
+    for (int g = 3; g < groups; g++) {
+        const float4 lst = g < 6 ? T.pack[(39 + g) * 64 + lane] : T.pack_ext[(g - 6) * 64 + lane];
+        const uint32_t sx[4] = {__float_as_uint(lst.x), __float_as_uint(lst.y), __float_as_uint(lst.z), __float_as_uint(lst.w)};
+        v2f ws[4], wm[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t a = sum0 + sx[u];
+            ws[u] = *reinterpret_cast<const lds_v2f *>((uintptr_t)a);
+            wm[u] = *reinterpret_cast<const lds_v2f *>((uintptr_t)(a + mxd));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            energy = energy + ws[u];
+            bmax.x = max_raw(bmax.x, wm[u].x);
+            bmax.y = max_raw(bmax.y, wm[u].y);
+        }
+    }
+    // lanes b / 32 + b hold the even-slot / odd-slot halves of band b for both channels. After the swap the first result
+    // has (channel 0 even | channel 1 even) and the second (channel 0 odd | channel 1 odd) on lanes (0..31 | 32..63).
+    {
+        const auto e2 = __builtin_amdgcn_permlane32_swap(__float_as_int(energy.x), __float_as_int(energy.y), false, false);
+        const auto m2 = __builtin_amdgcn_permlane32_swap(__float_as_int(bmax.x), __float_as_int(bmax.y), false, false);
+        energy1 = __int_as_float(e2[0]) + __int_as_float(e2[1]);
+        bmax1 = max_raw(__int_as_float(m2[0]), __int_as_float(m2[1]));
+    }
     wave_sync();
 }
 
@@ -959,8 +1007,8 @@ __device__ __forceinline__ void quantise_2(const int lane, const v2f (&c)[16], c
     typedef __attribute__((address_space(3))) v4f lds_f4;
     const uint32_t ts0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)L.u.a.ts);
     const uint32_t sgn_mask = 0x7FFFFFFFu;
-    uint32_t phalf = 0x3EFFFFFFu, zero = 0u;
-    asm volatile("" : "+v"(phalf), "+v"(zero));   // kept in registers: VOP3 / SDWA operands cannot be literals
+    uint32_t phalf = 0x3EFFFFFFu;
+    asm volatile("" : "+v"(phalf));   // kept in a register: a VOP3 operand cannot be a literal
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const float4 al4 = T.pack[(20 + g) * 64 + lane];
@@ -977,8 +1025,9 @@ __device__ __forceinline__ void quantise_2(const int lane, const v2f (&c)[16], c
             const v2f x = c[4 * g + k];
             const v2f xsc = x * (v2f){tb[k].z, tb[k].w};
             uint32_t h0, h1;
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(h0) : "s"(sgn_mask), "v"(phalf), "v"(xsc.x));
-            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(h1) : "s"(sgn_mask), "v"(phalf), "v"(xsc.y));
+            // sign of the product = sign of the coefficient (scale factors are positive): no wait for the multiplication
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(h0) : "s"(sgn_mask), "v"(phalf), "v"(x.x));
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(h1) : "s"(sgn_mask), "v"(phalf), "v"(x.y));
             const v2f rs = xsc + (v2f){__uint_as_float(h0), __uint_as_float(h1)};
             v[0][k] = cvt_rz(rs.x);
             v[1][k] = cvt_rz(rs.y);
@@ -994,11 +1043,11 @@ __device__ __forceinline__ void quantise_2(const int lane, const v2f (&c)[16], c
                 uint32_t r;
                 // keep iff |c| > thr (a NaN coefficient compares false like the reference, and converted to 0 anyway)
                 asm("v_cmp_gt_f32_e64 vcc, |%1|, %2\n\t"
-                    "v_cndmask_b32_e32 %0, %3, %4, vcc\n\t"
-                    "v_cmp_gt_f32_e64 vcc, |%5|, %6\n\t"
-                    "v_cndmask_b32_sdwa %0, %3, %7, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                    "v_cndmask_b32_e32 %0, 0, %3, vcc\n\t"
+                    "v_cmp_gt_f32_e64 vcc, |%4|, %5\n\t"
+                    "v_cndmask_b32_sdwa %0, 0, %6, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
                     : "=&v"(r)
-                    : "v"(xe), "v"(t[ch][2 * k2]), "v"(zero), "v"(v[ch][2 * k2]), "v"(xo), "v"(t[ch][2 * k2 + 1]), "v"(v[ch][2 * k2 + 1])
+                    : "v"(xe), "v"(t[ch][2 * k2]), "v"(v[ch][2 * k2]), "v"(xo), "v"(t[ch][2 * k2 + 1]), "v"(v[ch][2 * k2 + 1])
                     : "vcc");
                 xs[ch][2 * g + k2] = r;
             }

@@ -13,6 +13,10 @@
 //   All forms produce identical bytes (tests compare them file by file).
 #include <stdlib.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "lossy_device.hpp"
 #include "lossy_kernels.hpp"
 #include "../../include/flo_synth.h"
@@ -731,7 +735,11 @@ static_assert(sizeof(Clip2xLds) % 16 == 0, "clip LDS block keeps 16-byte alignme
 #endif
 // COEFFS: the spectra come from A.in_coeffs (the quantiser-only test entry) instead of the transform. A compile-time
 // switch: as a run-time branch the two sources met in a phi and every frame paid 32 register copies for it.
-template <bool COEFFS>
+// DIRTY: the element positions (bit e of 16) at which some lane of the band table closes a segment; the other positions
+// skip the slot store and the restart multiplication of band_stats_2. 0xFFFF serves every table; the launcher picks the
+// instantiation made for 44.1 kHz when the table agrees.
+constexpr uint32_t kDirty44k = 0xBDBEu;
+template <bool COEFFS, uint32_t DIRTY>
 __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArgs A, int clips_per_wg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int tid = (int)threadIdx.x;
@@ -956,22 +964,21 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             }
         }
         // band statistics, masking level, temporal masking, scale factors (analyse_frame, both channels)
-        v2f energy, bmax;
-        band_stats_2(ln, c, lds, T, energy, bmax);
+        float energy1, bmax1;   // channel 0's band b on lane b, channel 1's on lane 32 + b
+        band_stats_2<DIRTY>(ln, c, lds, T, energy1, bmax1);
         FLO_MARK("bandstats_done");
         STAMP(4);
-#ifndef FLO_SPLIT_MASK
         // masking level, temporal step and scale factors of both channels in one pass: channel 0 on lanes 0..24, channel 1
         // on lanes 32..56 (band_stats_2 leaves every band's totals in both halves)
         const int bnd = ln & 31, up = ln >> 5;
         const float rcount = T.pack[26 * 64 + bnd].z;
         uint32_t sfw1;
         {
-            const float a = spread_threshold_2(ln, up ? energy.y : energy.x, rcount, T);
+            const float a = spread_threshold_2(ln, energy1, rcount, T);
             const float sl = max_raw(a, prev[0] * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
             prev[0] = sl;
             const float tl1 = masking_amplitude(sl, T.smr_thr);
-            const float bm = up ? bmax.y : bmax.x;
+            const float bm = bmax1;
             const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
             sfw1 = sf_word(sfv1);
             if (bnd < 25) {
@@ -1008,47 +1015,6 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         set_counter(&cs.ready[1], fbase + h + 1);
         FLO_MARK("frame_end");
         STAMP(8);
-#else
-        const float rcount = T.pack[26 * 64 + ln].z;
-        uint32_t sfw[2];
-        float tl[2], sfv[2];
-#pragma unroll
-        for (int ch = 0; ch < 2; ch++) {
-            const float a = spread_threshold(ln, ch ? energy.y : energy.x, rcount, T);
-            const float sl = max_raw(a, prev[ch] * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
-            prev[ch] = sl;
-            tl[ch] = masking_amplitude(sl, T.smr_thr);
-            const float bm = ch ? bmax.y : bmax.x;
-            sfv[ch] = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
-            sfw[ch] = sf_word(sfv[ch]);
-        }
-        if (ln < 25) lds.u.a.ts[ln] = make_float4(tl[0], tl[1], sfv[0], sfv[1]);
-        wave_sync();
-        uint32_t xs[2][8];
-        quantise_2(ln, c, lds, T, xs);
-        if (A.dbg_q) {
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++) {
-                uint32_t *dq = reinterpret_cast<uint32_t *>(A.dbg_q + ((frame0 + h) * 2 + ch) * 1024 + 16 * ln);
-#pragma unroll
-                for (int k = 0; k < 8; k++) dq[k] = xs[ch][k];
-            }
-        }
-        if (A.dbg_sfw && ln < 25) {
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++) A.dbg_sfw[((frame0 + h) * 2 + ch) * 25 + ln] = (unsigned short)sfw[ch];
-        }
-        wait_counter(&cs.consumed, fbase + h);   // the packer has taken the previous frame out of the hand-over buffer
-#pragma unroll
-        for (int ch = 0; ch < 2; ch++) {
-            uint4 *dq = reinterpret_cast<uint4 *>(cs.qh[ch]);
-            dq[ln] = make_uint4(xs[ch][0], xs[ch][1], xs[ch][2], xs[ch][3]);
-            dq[64 + ln] = make_uint4(xs[ch][4], xs[ch][5], xs[ch][6], xs[ch][7]);
-            if (ln < 25) cs.sfwh[ch][ln] = (uint16_t)sfw[ch];
-        }
-        set_counter(&cs.ready[0], fbase + h + 1);
-        set_counter(&cs.ready[1], fbase + h + 1);
-#endif
     };
     for (unsigned h = 0; h < hops; h += 2) {
         frame_body(h, ae, ao, be, bo);
@@ -1165,11 +1131,11 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
             for (int e = 0; e < 16; e++) d[e] = ch ? c[e].y : c[e].x;
         }
     }
-    v2f energy, bmax;
-    band_stats_2(lane, c, lds, T, energy, bmax);
+    float energy1, bmax1;   // channel 0's band b on lane b, channel 1's on lane 32 + b
+    band_stats_2(lane, c, lds, T, energy1, bmax1);
     const int bnd = lane & 31, up = lane >> 5;
     const float rcount = T.pack[26 * 64 + bnd].z;
-    const float a = spread_threshold_2(lane, up ? energy.y : energy.x, rcount, T);
+    const float a = spread_threshold_2(lane, energy1, rcount, T);
     if (PASS == 1) {
         if (bnd < 25) A.a_t[(gframe * 2 + up) * 32 + bnd] = a;
         return;
@@ -1177,7 +1143,7 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
     const float prev = bnd < 25 ? A.s_prev[(gframe * 2 + up) * 32 + bnd] : 0.f;
     const float sl = max_raw(a, prev * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
     const float tl1 = masking_amplitude(sl, T.smr_thr);
-    const float bm = up ? bmax.y : bmax.x;
+    const float bm = bmax1;
     const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
     const uint32_t sfw1 = sf_word(sfv1);
     if (bnd < 25) {
@@ -1554,6 +1520,22 @@ __global__ void synth_fill_kernel(float *pcm, const unsigned long long *clip_off
         if (e_ != hipSuccess) return (int)e_;  \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set once per (device, kernel), from
+// whichever thread launches first on that device (contexts on several GPUs may live in one process).
+static int allow_big_lds(const void *fn) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count({dev, fn})) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    done.insert({dev, fn});
+    return 0;
+}
+
 // clips per workgroup: as few as fill the chip once (256 CUs), at most what 160 KiB of LDS holds
 int chain_clips_per_wg(int n_clips) {
     int g = (n_clips + 255) / 256;
@@ -1567,13 +1549,7 @@ template <int NW, bool EXACT>
 static int launch_chain_t(const LossyArgs &A, hipStream_t s) {
     const int g = chain_clips_per_wg(A.n_clips);
     const size_t lds = kPackBytes + (size_t)g * sizeof(ClipLds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lossy_chain_kernel<NW, EXACT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc = allow_big_lds(reinterpret_cast<const void *>(&lossy_chain_kernel<NW, EXACT>))) return rc;
     const unsigned wgs = (unsigned)((A.n_clips + g - 1) / g);
     hipLaunchKernelGGL((lossy_chain_kernel<NW, EXACT>), dim3(wgs), dim3(64 * NW * g), lds, s, A, g);
     FLO_LAUNCH_CHECK();
@@ -1592,13 +1568,7 @@ template <bool EXACT>
 static int launch_chain3_t(const LossyArgs &A, hipStream_t s) {
     const int g = chain3_clips_per_wg(A.n_clips);
     const size_t lds = kPackBytes + (size_t)g * sizeof(Clip3Lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lossy_chain3_kernel<EXACT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc = allow_big_lds(reinterpret_cast<const void *>(&lossy_chain3_kernel<EXACT>))) return rc;
     const unsigned wgs = (unsigned)((A.n_clips + g - 1) / g);
     hipLaunchKernelGGL((lossy_chain3_kernel<EXACT>), dim3(wgs), dim3(192 * g), lds, s, A, g);
     FLO_LAUNCH_CHECK();
@@ -1612,7 +1582,7 @@ int chain2x_clips_per_wg(int n_clips) {
     if (g > FLO_C2X_THREADS / 128) g = FLO_C2X_THREADS / 128;   // twelve waves: three per SIMD (up to 168 registers each)
     return g < 1 ? 1 : g;
 }
-template <bool COEFFS>
+template <bool COEFFS, uint32_t DIRTY>
 static int launch_chain2x_t(const LossyArgs &A, hipStream_t s) {
     int g = chain2x_clips_per_wg(A.n_clips);
     if (const char *e = getenv("FLO_CHAIN2X_CLIPS")) {   // diagnostic: clips per workgroup
@@ -1620,22 +1590,17 @@ static int launch_chain2x_t(const LossyArgs &A, hipStream_t s) {
         if (v >= 1 && v <= FLO_C2X_THREADS / 128) g = v;
     }
     const size_t lds = kPackBytes + (size_t)g * sizeof(Clip2xLds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lossy_chain2x_kernel<COEFFS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc = allow_big_lds(reinterpret_cast<const void *>(&lossy_chain2x_kernel<COEFFS, DIRTY>))) return rc;
     unsigned wgs = (unsigned)((A.n_clips + g - 1) / g);
     if (A.n_cus > 0 && wgs > (unsigned)A.n_cus) wgs = (unsigned)A.n_cus;   // persistent: one workgroup per CU, clips dealt dynamically
-    hipLaunchKernelGGL((lossy_chain2x_kernel<COEFFS>), dim3(wgs), dim3(128 * g), lds, s, A, g);
+    hipLaunchKernelGGL((lossy_chain2x_kernel<COEFFS, DIRTY>), dim3(wgs), dim3(128 * g), lds, s, A, g);
     FLO_LAUNCH_CHECK();
     return 0;
 }
 int launch_lossy_chain2x(const LossyArgs &A, hipStream_t s) {
     if (A.nch != 2 || A.exact) return -1;   // the exact-threshold test yardstick lives in the other forms
-    return A.in_coeffs ? launch_chain2x_t<true>(A, s) : launch_chain2x_t<false>(A, s);
+    if (A.in_coeffs) return launch_chain2x_t<true, 0xFFFFu>(A, s);
+    return (A.T.dirty | 0x8000u) == kDirty44k ? launch_chain2x_t<false, kDirty44k>(A, s) : launch_chain2x_t<false, 0xFFFFu>(A, s);
 }
 
 int launch_lossy_chain3(const LossyArgs &A, hipStream_t s) {

@@ -159,6 +159,8 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
         }
     }
     t.n_slots = (int)slot_band.size();
+    t.dirty = 0;
+    for (int j = 0; j < 64; j++) t.dirty |= t.lane_bnd[j];
     t.band_slot0.assign(kNumBands + 1, 0);
     // slots are generated in k order, so each band's slots are consecutive
     int s = 0;

@@ -39,6 +39,7 @@ struct LossyTablesHost {
     std::vector<uint32_t> lane_slot0;  // [64] index of the lane's first segment slot
     std::vector<uint32_t> band_slot0;  // [26] slots of band b are [band_slot0[b], band_slot0[b+1])
     int max_band_slots = 0;            // max over bands of slot count
+    uint32_t dirty = 0;                // OR of lane_bnd over the lanes: element positions at which some lane closes a segment
     int n_slots = 0;
 };
 
