@@ -739,7 +739,9 @@ static_assert(sizeof(Clip2xLds) % 16 == 0, "clip LDS block keeps 16-byte alignme
 // skip the slot store and the restart multiplication of band_stats_2. 0xFFFF serves every table; the launcher picks the
 // instantiation made for 44.1 kHz when the table agrees.
 constexpr uint32_t kDirty44k = 0xBDBEu;
-template <bool COEFFS, uint32_t DIRTY>
+// DBG: the stage outputs of the test entry points (coefficients, integers, scale words) are stored; the encode entry
+// points run the instantiation without them (no pointer tests, fewer live scalars in the frame loop).
+template <bool COEFFS, uint32_t DIRTY, bool DBG>
 __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArgs A, int clips_per_wg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     const int tid = (int)threadIdx.x;
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
                 uint32_t t = sparse_list_emit(ln, SL[ch], f_a + pos + 4u, tab_a, lst_a[ch]);
-                if (t == kSparseFallback) {   // uniform: dense frame (many non-zeros or runs, a run longer than 255)
+                if (t == kSparseFallback) {   // uniform: dense frame (many runs, a run longer than 255)
                     int q[1][16];
                     uint32_t hi[8];
 #pragma unroll
@@ -954,7 +956,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             FLO_MARK("postrot_done");
             STAMP(3);
 
-            if (A.dbg_coeffs) {
+            if (DBG && A.dbg_coeffs) {
 #pragma unroll
                 for (int ch = 0; ch < 2; ch++) {
                     float *d = A.dbg_coeffs + ((frame0 + h) * 2 + ch) * 1024 + 16 * ln;
@@ -993,7 +995,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         quantise_2(ln, c, lds, T, xs);
         FLO_MARK("quant_done");
         STAMP(6);
-        if (A.dbg_q) {
+        if (DBG && A.dbg_q) {
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
                 uint32_t *dq = reinterpret_cast<uint32_t *>(A.dbg_q + ((frame0 + h) * 2 + ch) * 1024 + 16 * ln);
@@ -1001,7 +1003,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
                 for (int k = 0; k < 8; k++) dq[k] = xs[ch][k];
             }
         }
-        if (A.dbg_sfw && bnd < 25) A.dbg_sfw[((frame0 + h) * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
+        if (DBG && A.dbg_sfw && bnd < 25) A.dbg_sfw[((frame0 + h) * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
         wait_counter(&cs.consumed, fbase + h);   // the packer has taken the previous frame out of the hand-over buffer
         STAMP(7);
 #pragma unroll
@@ -1582,7 +1584,7 @@ int chain2x_clips_per_wg(int n_clips) {
     if (g > FLO_C2X_THREADS / 128) g = FLO_C2X_THREADS / 128;   // twelve waves: three per SIMD (up to 168 registers each)
     return g < 1 ? 1 : g;
 }
-template <bool COEFFS, uint32_t DIRTY>
+template <bool COEFFS, uint32_t DIRTY, bool DBG>
 static int launch_chain2x_t(const LossyArgs &A, hipStream_t s) {
     int g = chain2x_clips_per_wg(A.n_clips);
     if (const char *e = getenv("FLO_CHAIN2X_CLIPS")) {   // diagnostic: clips per workgroup
@@ -1590,17 +1592,18 @@ static int launch_chain2x_t(const LossyArgs &A, hipStream_t s) {
         if (v >= 1 && v <= FLO_C2X_THREADS / 128) g = v;
     }
     const size_t lds = kPackBytes + (size_t)g * sizeof(Clip2xLds);
-    if (int rc = allow_big_lds(reinterpret_cast<const void *>(&lossy_chain2x_kernel<COEFFS, DIRTY>))) return rc;
+    if (int rc = allow_big_lds(reinterpret_cast<const void *>(&lossy_chain2x_kernel<COEFFS, DIRTY, DBG>))) return rc;
     unsigned wgs = (unsigned)((A.n_clips + g - 1) / g);
     if (A.n_cus > 0 && wgs > (unsigned)A.n_cus) wgs = (unsigned)A.n_cus;   // persistent: one workgroup per CU, clips dealt dynamically
-    hipLaunchKernelGGL((lossy_chain2x_kernel<COEFFS, DIRTY>), dim3(wgs), dim3(128 * g), lds, s, A, g);
+    hipLaunchKernelGGL((lossy_chain2x_kernel<COEFFS, DIRTY, DBG>), dim3(wgs), dim3(128 * g), lds, s, A, g);
     FLO_LAUNCH_CHECK();
     return 0;
 }
 int launch_lossy_chain2x(const LossyArgs &A, hipStream_t s) {
     if (A.nch != 2 || A.exact) return -1;   // the exact-threshold test yardstick lives in the other forms
-    if (A.in_coeffs) return launch_chain2x_t<true, 0xFFFFu>(A, s);
-    return (A.T.dirty | 0x8000u) == kDirty44k ? launch_chain2x_t<false, kDirty44k>(A, s) : launch_chain2x_t<false, 0xFFFFu>(A, s);
+    if (A.in_coeffs) return launch_chain2x_t<true, 0xFFFFu, true>(A, s);
+    if (A.dbg_coeffs || A.dbg_q || A.dbg_sfw) return launch_chain2x_t<false, 0xFFFFu, true>(A, s);
+    return (A.T.dirty | 0x8000u) == kDirty44k ? launch_chain2x_t<false, kDirty44k, false>(A, s) : launch_chain2x_t<false, 0xFFFFu, false>(A, s);
 }
 
 int launch_lossy_chain3(const LossyArgs &A, hipStream_t s) {
