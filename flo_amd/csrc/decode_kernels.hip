@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
                     const float se = sf[D.T.band[ke]], so = sf[D.T.band[ko]];
                     const float even = (float)q[ke] * se;   // se, so: 1 / scale factor, 0 for a band without one
                     const float odd = -((float)q[ko] * so);
-                    const float4 t4 = D.T.pack[(8 + (r >> 1)) * 64 + lane];
+                    const float4 t4 = D.T.pack[(kRowTw + (r >> 1)) * 64 + lane];
                     const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
                     zr[0][r] = odd * w.y - even * w.x;
                     zi[0][r] = odd * w.x + even * w.y;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const int idx = lane + 64 * r;
-                    const float4 t4 = D.T.pack[(8 + (r >> 1)) * 64 + lane];
+                    const float4 t4 = D.T.pack[(kRowTw + (r >> 1)) * 64 + lane];
                     const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
                     const float val_re = w.x * zr[0][r] + w.y * zi[0][r];
                     const float val_im = w.y * zr[0][r] - w.x * zi[0][r];

@@ -267,6 +267,7 @@ static int get_tables(flo_ctx *c, uint32_t sr, float quality, TableSet **out) {
     }
     auto P = [&](size_t i) { return (const char *)t->blob + parts[i].off; };
     t->dev.pack = (const float4 *)P(i_pack);
+    t->dev.pack_g = t->dev.pack;
     t->dev.pack_ext = (const float4 *)P(i_ext);
     t->dev.ath_db = (const float *)P(i_athdb);
     t->dev.band = (const uint8_t *)P(i_band);
@@ -710,7 +711,10 @@ static int batch_sync_impl(flo_batch *b, hipEvent_t done) {
                     for (int i = 0; i < 9; i++) { fprintf(stderr, " %s=%.1f", tn[i], t[i] / b->total_frames); tt += t[i]; }
                     fprintf(stderr, " total=%.1f | P:", tt / b->total_frames);
                     for (int i = 0; i < 5; i++) { fprintf(stderr, " %s=%.1f", pn[i], p[i] / b->total_frames); pt += p[i]; }
-                    fprintf(stderr, " total=%.1f\n", pt / b->total_frames);
+                    fprintf(stderr, " total=%.1f", pt / b->total_frames);
+                    fprintf(stderr, " | T waits>1000: %.2f%% of frames, %.0f cyc/frame avg; >5000: %.2f%%, %.0f | P busy>12000: %.2f%%, %.0f; >20000: %.2f%%, %.0f\n",
+                            100 * t[10] / b->total_frames, t[9] / b->total_frames, 100 * t[12] / b->total_frames, t[11] / b->total_frames,
+                            100 * p[10] / b->total_frames, p[9] / b->total_frames, 100 * p[12] / b->total_frames, p[11] / b->total_frames);
                 }
                 static const char *nm[] = {"wait-loads+fold", "issue-loads", "fft", "postrot", "analyse(bands,psy,quant,plan)",
                                            "sync-tot", "emit", "sync-emit", "flush", "sync-tail"};

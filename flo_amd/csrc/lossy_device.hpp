@@ -19,24 +19,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pack_rows.h"
+
 namespace flo {
 
-// Per-lane constant pack, laid out [row][lane] as float4 so that one wave-wide load is 1 KiB contiguous:
-//   rows 0..7   : window values of fold row r: (w[eo], w[oo], w[1024+eo], w[1024+oo])      (mdct.rs:106-113)
-//   rows 8..11  : pre/post-rotation twiddles tw[lane + 64 r], two rows per float4           (mdct.rs:81-86)
-//   rows 12..15 : FFT pass-1 twiddles W512^(lane k), k = 1..7 (re,im pairs, last pair unused)
-//   rows 16..19 : FFT pass-2 twiddles W64^((lane&7) k), k = 1..7
-//   rows 20..23 : ATH amplitude thresholds of coefficients 16 lane .. 16 lane + 15
-//   rows 24..26 : per-lane band bookkeeping of the contiguous layout (see load_lane_const)
-//   rows 27..30 : byte offset into bandv of each of the lane's 16 coefficients
-//   rows 31..34 : band-statistics keep multipliers (0.0 after a band boundary, else 1.0)
-//   rows 35..38 : byte offset of the slot each running (sum, max) is stored to (segment slot or the lane's trash slot)
-//   rows 39..44 : byte offsets of the up to 24 slots this band lane adds (zero slot when exhausted)
-//   row  45     : not per lane - floats 0..23 are s10d[1..24] (spreading level per band distance), read uniformly
-constexpr int kPackRows = 46;
+// Per-lane constant pack, laid out [row][lane] as float4 so that one wave-wide load is 1 KiB contiguous; the rows are
+// listed in pack_rows.h (kRowWin ... kRowLstCold).
 
 struct LossyDevTables {
-    const float4 *pack;      // [kPackRows][64]
+    const float4 *pack;      // [kPackRows][64]; kernels that copy the pack to LDS point this at their copy ...
+    const float4 *pack_g;    // ... and keep the global copy here (rows from kPackRowsHot on may not be in LDS)
     const float4 *pack_ext;  // [2][64] slot-list groups 6, 7 (global memory; sample rates from 128 kHz up)
     const float *ath_db;     // [1024]
     const uint8_t *band;     // [1024]
@@ -199,7 +191,7 @@ __device__ __forceinline__ void fft512(const int lane, float (&zr)[CH][8], float
     for (int c = 0; c < CH; c++) dft8(zr[c], zi[c]);
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
-        const float4 w = T.pack[(12 + kk) * 64 + lane];
+        const float4 w = T.pack[(kRowF1 + kk) * 64 + lane];
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             cmul(zr[c][2 * kk + 1], zi[c][2 * kk + 1], w.x, w.y);
@@ -232,7 +224,7 @@ __device__ __forceinline__ void fft512(const int lane, float (&zr)[CH][8], float
     for (int c = 0; c < CH; c++) dft8(zr[c], zi[c]);
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
-        const float4 w = T.pack[(16 + kk) * 64 + lane];
+        const float4 w = T.pack[(kRowF2 + kk) * 64 + lane];
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             cmul(zr[c][2 * kk + 1], zi[c][2 * kk + 1], w.x, w.y);
@@ -345,9 +337,9 @@ __device__ __forceinline__ void fold(const int lane, const float (&ae)[CH][8], c
                                      const LossyDevTables &T) {
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const float4 ww = T.pack[r * 64 + lane];
+        const float4 ww = T.pack[(kRowWin + r) * 64 + lane];
         const float wae = ww.x, wao = ww.y, wbe = ww.z, wbo = ww.w;
-        const float4 t4 = T.pack[(8 + (r >> 1)) * 64 + lane];
+        const float4 t4 = T.pack[(kRowTw + (r >> 1)) * 64 + lane];
         const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
 #pragma unroll
         for (int c = 0; c < CH; c++) {
@@ -382,7 +374,7 @@ __device__ __forceinline__ void post_rotate_transpose(const int lane, const floa
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int m = lane + 64 * r;
-        const float4 t4 = T.pack[(8 + (r >> 1)) * 64 + lane];
+        const float4 t4 = T.pack[(kRowTw + (r >> 1)) * 64 + lane];
         const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
         const int k0 = 2 * m, k1 = 1023 - 2 * m;
 #ifdef FLO_COEF_PAD16
@@ -475,7 +467,7 @@ __device__ __forceinline__ void fft512_2(const int lane, v2f (&zr)[8], v2f (&zi)
     dft8_2(zr, zi);
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
-        const float4 w = T.pack[(12 + kk) * 64 + lane];
+        const float4 w = T.pack[(kRowF1 + kk) * 64 + lane];
         cmul_2(zr[2 * kk + 1], zi[2 * kk + 1], w.x, w.y);
         if (kk < 3) cmul_2(zr[2 * kk + 2], zi[2 * kk + 2], w.z, w.w);
     }
@@ -495,7 +487,7 @@ __device__ __forceinline__ void fft512_2(const int lane, v2f (&zr)[8], v2f (&zi)
     dft8_2(zr, zi);
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
-        const float4 w = T.pack[(16 + kk) * 64 + lane];
+        const float4 w = T.pack[(kRowF2 + kk) * 64 + lane];
         cmul_2(zr[2 * kk + 1], zi[2 * kk + 1], w.x, w.y);
         if (kk < 3) cmul_2(zr[2 * kk + 2], zi[2 * kk + 2], w.z, w.w);
     }
@@ -539,9 +531,9 @@ __device__ __forceinline__ void fold_2(const int lane, const v2f (&ae)[8], const
                                        v2f (&zr)[8], v2f (&zi)[8], const LossyDevTables &T) {
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const float4 ww = T.pack[r * 64 + lane];
+        const float4 ww = T.pack[(kRowWin + r) * 64 + lane];
         const v2f wae = splat2(ww.x), wao = splat2(ww.y), wbe = splat2(ww.z), wbo = splat2(ww.w);
-        const float4 t4 = T.pack[(8 + (r >> 1)) * 64 + lane];
+        const float4 t4 = T.pack[(kRowTw + (r >> 1)) * 64 + lane];
         const v2f wx = splat2((r & 1) ? t4.z : t4.x), wy = splat2((r & 1) ? t4.w : t4.y);
         v2f re, im;
         if (r < 4) {
@@ -566,7 +558,7 @@ __device__ __forceinline__ void post_rotate_transpose_2(const int lane, const v2
     float2 *const w1 = c2 + (1149 - 7 * 144) - pl;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const float4 t4 = T.pack[(8 + (r >> 1)) * 64 + lane];
+        const float4 t4 = T.pack[(kRowTw + (r >> 1)) * 64 + lane];
         const v2f wx = splat2((r & 1) ? t4.z : t4.x), wy = splat2((r & 1) ? t4.w : t4.y);
         const v2f R = fma2(-zi[r], wy, -(zr[r] * wx));
         const v2f I = fma2(zi[r], wx, -(zr[r] * wy));
@@ -592,7 +584,7 @@ struct LaneConst {
 // Band b is reduced by lane b (even slots of the band) and lane 32 + b (odd slots); lane b adds the two halves.
 
 __device__ __forceinline__ void load_lane_const(const int lane, LaneConst &L, const LossyDevTables &T) {
-    L.rcount = T.pack[26 * 64 + lane].z;
+    L.rcount = T.pack[kRowLane * 64 + lane].z;
 }
 
 constexpr int kZeroSlot = kSlotCap + 64;
@@ -613,15 +605,15 @@ __device__ __forceinline__ void band_stats(const int lane, const float (&c)[CH][
     uint32_t dv[16], so[12];
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        const float4 keep = T.pack[(31 + g) * 64 + lane];
-        const float4 dsto = T.pack[(35 + g) * 64 + lane];
+        const float4 keep = T.pack[(kRowKeep + g) * 64 + lane];
+        const float4 dsto = T.pack[(kRowDst + g) * 64 + lane];
         kp[4 * g + 0] = keep.x, kp[4 * g + 1] = keep.y, kp[4 * g + 2] = keep.z, kp[4 * g + 3] = keep.w;
         dv[4 * g + 0] = __float_as_uint(dsto.x), dv[4 * g + 1] = __float_as_uint(dsto.y);
         dv[4 * g + 2] = __float_as_uint(dsto.z), dv[4 * g + 3] = __float_as_uint(dsto.w);
     }
 #pragma unroll
     for (int g = 0; g < 3; g++) {
-        const float4 lst = T.pack[(39 + g) * 64 + lane];
+        const float4 lst = T.pack[(kRowLst + g) * 64 + lane];
         so[4 * g + 0] = __float_as_uint(lst.x), so[4 * g + 1] = __float_as_uint(lst.y);
         so[4 * g + 2] = __float_as_uint(lst.z), so[4 * g + 3] = __float_as_uint(lst.w);
     }
@@ -666,7 +658,7 @@ __device__ __forceinline__ void band_stats(const int lane, const float (&c)[CH][
         }
     const int groups = (T.max_band_slots + 7) >> 3;  // 4 list entries per group, each lane takes every other slot
     for (int g = 3; g < groups; g++) {
-        const float4 lst = g < 6 ? T.pack[(39 + g) * 64 + lane] : T.pack_ext[(g - 6) * 64 + lane];
+        const float4 lst = g < 6 ? T.pack_g[(kRowLstCold + g - 3) * 64 + lane] : T.pack_ext[(g - 6) * 64 + lane];
         const uint32_t sx[4] = {__float_as_uint(lst.x), __float_as_uint(lst.y), __float_as_uint(lst.z), __float_as_uint(lst.w)};
         float2 vx[CH][4];
 #pragma unroll
@@ -694,7 +686,7 @@ __device__ __forceinline__ void band_stats(const int lane, const float (&c)[CH][
 // 10 log10(e / n) is evaluated as (10 log10 2) * log2(e * (1/n)) with the hardware log2 (1 ulp): the thresholds it
 // feeds are compared at the 1e-6 level by both implementations.
 __device__ __forceinline__ float spread_threshold(const int lane, float energy, float rcount, const LossyDevTables &T) {
-    const float4 sd0 = T.pack[45 * 64], sd1 = T.pack[45 * 64 + 1];
+    const float4 sd0 = T.pack[kRowS10 * 64], sd1 = T.pack[kRowS10 * 64 + 1];
     const bool is_band = lane < 25;
     float band_db = -100.0f;
     if (is_band && rcount > 0.f && energy > 1e-10f) band_db = 3.01029995663981195f * __builtin_amdgcn_logf(energy * rcount);
@@ -727,7 +719,7 @@ __device__ __forceinline__ float spread_threshold(const int lane, float energy, 
             int d = (int)((gmax + 100.0f) * (1.0f / 24.9f)) + 1;
             dmax = d < 1 ? 1 : (d > 24 ? 24 : d);
         }
-        const float *srow = reinterpret_cast<const float *>(T.pack + 45 * 64);
+        const float *srow = reinterpret_cast<const float *>(T.pack + kRowS10 * 64);
         for (int d = 9; d <= dmax; d++) {
             cur = dpp_f<0x138>(ninf, cur);
             m = max_raw(m, cur + srow[d - 1]);
@@ -736,12 +728,31 @@ __device__ __forceinline__ float spread_threshold(const int lane, float energy, 
     return m + (-6.0f);
 }
 
+// x = max(x, x of the lane CTRL names); lanes without a source keep x. One instruction: the maximum itself carries the
+// DPP modifier (the generic dpp_f + max_raw pair costs a constant load, a move and the maximum). The s_nop covers the
+// two wait states a DPP read needs behind the vector write of its source.
+template <int CTRL>
+__device__ __forceinline__ float max_self_dpp(float x) {
+    static_assert(CTRL == 0x101 || CTRL == 0x102 || CTRL == 0x104 || CTRL == 0x108, "row_shl:1/2/4/8");
+    if (CTRL == 0x101) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    if (CTRL == 0x102) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    if (CTRL == 0x104) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    if (CTRL == 0x108) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf" : "+v"(x));
+    return x;
+}
+// value of lane - 1, lane 0 receives lane 63's (wave_ror:1): every lane has a source, so no `old` operand to prepare
+__device__ __forceinline__ float ror1(float x) {
+    float r;
+    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // The same for both channels of a stereo frame in ONE pass: channel 0's bands on lanes 0..24, channel 1's on lanes
 // 32..56 (band = lane & 31). Every lane goes through exactly the operations of spread_threshold; what differs is the
 // bookkeeping between the halves: the row-0 / row-2 lanes take bands 16..24 from lane 16 / 48, and the shifted copy of
 // channel 0's band 24 is kept from reaching channel 1's band 0 (it arrives at lane 32 after exactly eight shifts).
 __device__ __forceinline__ float spread_threshold_2(const int lane, float energy, float rcount, const LossyDevTables &T) {
-    const float4 sd0 = T.pack[45 * 64], sd1 = T.pack[45 * 64 + 1];
+    const float4 sd0 = T.pack[kRowS10 * 64], sd1 = T.pack[kRowS10 * 64 + 1];
     const int b = lane & 31;
     const bool is_band = b < 25;
     float band_db = -100.0f;
@@ -749,20 +760,24 @@ __device__ __forceinline__ float spread_threshold_2(const int lane, float energy
     if (!is_band) band_db = -__builtin_inff();
     const float ninf = -__builtin_inff();
     float sm = band_db;
-    sm = max_raw(sm, dpp_f<0x101>(ninf, sm));
-    sm = max_raw(sm, dpp_f<0x102>(ninf, sm));
-    sm = max_raw(sm, dpp_f<0x104>(ninf, sm));
-    sm = max_raw(sm, dpp_f<0x108>(ninf, sm));
+    sm = max_self_dpp<0x101>(sm);
+    sm = max_self_dpp<0x102>(sm);
+    sm = max_self_dpp<0x104>(sm);
+    sm = max_self_dpp<0x108>(sm);
     const float hi0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 16));
     const float hi1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 48));
     if (b < 16) sm = max_raw(sm, lane < 32 ? hi0 : hi1);
     float m = max_raw(-100.0f, sm);
     float cur = band_db;
     const float sd[8] = {sd0.x, sd0.y, sd0.z, sd0.w, sd1.x, sd1.y, sd1.z, sd1.w};
+    // The copies are ROTATED by one lane per step: what enters lane 0 (channel 0's band 0) comes from lanes 63, 62, ...,
+    // which are idle lanes holding -inf, exactly like the lanes 31, 30, ... that feed channel 1's band 0 on lane 32. At
+    // the eighth step the values that started on lanes 24 and 56 (band 24 of either channel) would arrive: they are cut
+    // off one step earlier, on lanes 31 and 63.
 #pragma unroll
     for (int d = 1; d <= 8; d++) {
-        if (d == 8) cur = lane == 31 ? ninf : cur;   // channel 0's band 24, seven shifts on: not channel 1's business
-        cur = dpp_f<0x138>(ninf, cur);  // wave_shr:1 -> band_db[lane - d]
+        if (d == 8) cur = (lane & 31) == 31 ? ninf : cur;
+        cur = ror1(cur);   // band_db[lane - d]
         m = max_raw(m, cur + sd[d - 1]);
     }
     const float g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 0));
@@ -774,7 +789,7 @@ __device__ __forceinline__ float spread_threshold_2(const int lane, float energy
             int d = (int)((gmax + 100.0f) * (1.0f / 24.9f)) + 1;
             dmax = d < 1 ? 1 : (d > 24 ? 24 : d);
         }
-        const float *srow = reinterpret_cast<const float *>(T.pack + 45 * 64);
+        const float *srow = reinterpret_cast<const float *>(T.pack + kRowS10 * 64);
         for (int d = 9; d <= dmax; d++) {
             cur = dpp_f<0x138>(ninf, cur);
             if (b < d) cur = ninf;   // came from below band 0 of this channel (the other channel's bands, or nothing)
@@ -823,8 +838,8 @@ __device__ __forceinline__ void quantise(const int lane, const float (&c)[CH][16
     uint32_t bo[16];
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        const float4 al4 = T.pack[(20 + g) * 64 + lane];
-        const float4 bo4 = T.pack[(27 + g) * 64 + lane];
+        const float4 al4 = T.pack[(kRowAth + g) * 64 + lane];
+        const float4 bo4 = T.pack[(kRowBo + g) * 64 + lane];
         al[4 * g + 0] = al4.x, al[4 * g + 1] = al4.y, al[4 * g + 2] = al4.z, al[4 * g + 3] = al4.w;
         bo[4 * g + 0] = __float_as_uint(bo4.x), bo[4 * g + 1] = __float_as_uint(bo4.y);
         bo[4 * g + 2] = __float_as_uint(bo4.z), bo[4 * g + 3] = __float_as_uint(bo4.w);
@@ -911,7 +926,7 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
 #ifndef FLO_BS_LATE_LISTS
 #pragma unroll
     for (int g = 0; g < 3; g++) {
-        const float4 lst = T.pack[(39 + g) * 64 + lane];
+        const float4 lst = T.pack[(kRowLst + g) * 64 + lane];
         so[4 * g + 0] = sum0 + __float_as_uint(lst.x), so[4 * g + 1] = sum0 + __float_as_uint(lst.y);
         so[4 * g + 2] = sum0 + __float_as_uint(lst.z), so[4 * g + 3] = sum0 + __float_as_uint(lst.w);
     }
@@ -920,8 +935,8 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
     v2f acc = splat2(0.f), mx = splat2(0.f);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        const float4 keep = T.pack[(31 + g) * 64 + lane];
-        const float4 dsto = T.pack[(35 + g) * 64 + lane];
+        const float4 keep = T.pack[(kRowKeep + g) * 64 + lane];
+        const float4 dsto = T.pack[(kRowDst + g) * 64 + lane];
         const float kp[4] = {keep.x, keep.y, keep.z, keep.w};
         const uint32_t dv[4] = {__float_as_uint(dsto.x), __float_as_uint(dsto.y), __float_as_uint(dsto.z), __float_as_uint(dsto.w)};
 #pragma unroll
@@ -944,7 +959,7 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
 #ifdef FLO_BS_LATE_LISTS
 #pragma unroll
     for (int g = 0; g < 3; g++) {
-        const float4 lst = T.pack[(39 + g) * 64 + lane];
+        const float4 lst = T.pack[(kRowLst + g) * 64 + lane];
         so[4 * g + 0] = sum0 + __float_as_uint(lst.x), so[4 * g + 1] = sum0 + __float_as_uint(lst.y);
         so[4 * g + 2] = sum0 + __float_as_uint(lst.z), so[4 * g + 3] = sum0 + __float_as_uint(lst.w);
     }
@@ -968,7 +983,7 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
     }
     const int groups = (T.max_band_slots + 7) >> 3;
     for (int g = 3; g < groups; g++) {
-        const float4 lst = g < 6 ? T.pack[(39 + g) * 64 + lane] : T.pack_ext[(g - 6) * 64 + lane];
+        const float4 lst = g < 6 ? T.pack_g[(kRowLstCold + g - 3) * 64 + lane] : T.pack_ext[(g - 6) * 64 + lane];
         const uint32_t sx[4] = {__float_as_uint(lst.x), __float_as_uint(lst.y), __float_as_uint(lst.z), __float_as_uint(lst.w)};
         v2f ws[4], wm[4];
 #pragma unroll
@@ -1001,8 +1016,19 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
 // maximum, one compare and one select; the select of an odd element writes the upper half of the even element's
 // register directly (SDWA), so nothing is spent on packing. (threshold, scale) of a coefficient's band come from ONE
 // 16-byte gather. Same arithmetic as quantise<., false>: bit-identical integers.
+// The band-offset rows of the quantiser (what its gathers wait for). The chain kernel fetches them BEFORE the masking
+// pass, whose long dependent chain then hides their latency.
+struct QuantRows {
+    float4 bo4[4];   // (the thresholds' rows are fetched next to the gathers: sixteen more registers would not fit)
+};
+__device__ __forceinline__ void quant_rows_load(const int lane, const LossyDevTables &T, QuantRows &R) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        R.bo4[g] = T.pack[(kRowBo + g) * 64 + lane];
+    }
+}
 __device__ __forceinline__ void quantise_2(const int lane, const v2f (&c)[16], const StereoLds &L, const LossyDevTables &T,
-                                           uint32_t (&xs)[2][8]) {
+                                           const QuantRows &R, uint32_t (&xs)[2][8]) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) v4f lds_f4;
     const uint32_t ts0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)L.u.a.ts);
@@ -1011,8 +1037,8 @@ __device__ __forceinline__ void quantise_2(const int lane, const v2f (&c)[16], c
     asm volatile("" : "+v"(phalf));   // kept in a register: a VOP3 operand cannot be a literal
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        const float4 al4 = T.pack[(20 + g) * 64 + lane];
-        const float4 bo4 = T.pack[(27 + g) * 64 + lane];
+        const float4 al4 = T.pack[(kRowAth + g) * 64 + lane];
+        const float4 bo4 = R.bo4[g];
         const float al[4] = {al4.x, al4.y, al4.z, al4.w};
         const uint32_t bo[4] = {__float_as_uint(bo4.x), __float_as_uint(bo4.y), __float_as_uint(bo4.z), __float_as_uint(bo4.w)};
         v4f tb[4];
@@ -1396,7 +1422,7 @@ __device__ __forceinline__ uint32_t sparse_ballot_pack(const int lane, const uin
 // than the run table holds, a run longer than 255 (continuation records). All of them are dense frames.
 // LDS scratch: tab = kRunTabEntries dwords; lst = kListCap dwords with TWO more dwords in front of it (lst - 8: the
 // inactive lanes' store target, lst - 4: the "position -1" sentinel).
-constexpr int kListCap = 256;
+constexpr int kListCap = 512;
 
 __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -1416,37 +1442,41 @@ struct SparseList {
     uint32_t last;    // position of the last non-zero (valid when n > 0)
 };
 
-__device__ __forceinline__ SparseList sparse_list_build(const int lane, const uint32_t (&x)[16], const uint32_t lst) {
-    uint32_t n = 0, last_hi = 0;
-    unsigned long long last_b = 1ull;
-    const uint32_t lane16 = (uint32_t)lane << 16;
-    const uint32_t amax = lst + 4u * (uint32_t)(kListCap - 1);
+// xd[k] (k = 0..7): the dword that holds positions 128 k + 2 lane (low half) and + 1 (high half), i.e. the hand-over
+// buffer in natural order read one dword per lane: lanes 0..31 cover one 64-position word, lanes 32..63 the next.
+// The non-zero ballots of the low and of the high halves together rank every non-zero in position order:
+//   rank(lane, low) = non-zeros of both ballots below the lane (four v_mbcnt), rank(lane, high) = that + (low != 0).
+// Once more than kListCap non-zeros have been counted nothing more is stored (the caller falls back).
+__device__ __forceinline__ SparseList sparse_list_build(const int lane, const uint32_t (&xd)[8], const uint32_t lst) {
+    uint32_t n = 0, last = 0;
+    const uint32_t pos0 = (uint32_t)(2 * lane) << 16;
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        // four ballots at a time: one wait for the vector unit's masks per group, one branch for four empty words
-        unsigned long long b[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) b[k] = __ballot(x[4 * g + k] != 0u);
-        if ((b[0] | b[1] | b[2] | b[3]) == 0ull) continue;   // uniform
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (b[k] == 0ull) continue;   // uniform
-            const int e = 4 * g + k;
-            uint32_t a = (mbcnt64(b[k]) << 2) + (lst + 4u * n);
-            a = a < amax ? a : amax;
-            const uint32_t ent = x[e] | lane16 | ((uint32_t)(64 * e) << 16);
+    for (int k = 0; k < 8; k++) {
+        const uint32_t lo = xd[k] & 0xFFFFu, hi = xd[k] >> 16;
+        const unsigned long long E = __ballot(lo != 0u), O = __ballot(hi != 0u);
+        const unsigned long long any = E | O;
+        if (any == 0ull) continue;   // uniform: 128 zeros
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(E) + (uint32_t)__builtin_popcountll(O);
+        if (n + cnt <= (uint32_t)kListCap) {   // uniform
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(O >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)O, mbcnt64(E)));
+            const uint32_t a_lo = (below << 2) + (lst + 4u * n);
+            const uint32_t a_hi = a_lo + (lo != 0u ? 4u : 0u);
+            const uint32_t pk = pos0 + ((uint32_t)(128 * k) << 16);
+            const uint32_t e_lo = lo | pk, e_hi = hi | (pk + 0x10000u);
             unsigned long long sv;
-            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %3, %4\n\t"
+                         "s_mov_b64 exec, %2\n\tds_write_b32 %5, %6\n\ts_mov_b64 exec, %0"
                          : "=&s"(sv)
-                         : "s"(b[k]), "v"(a), "v"(ent));
-            n += (uint32_t)__builtin_popcountll(b[k]);
-            last_hi = (uint32_t)(64 * e);
-            last_b = b[k];
+                         : "s"(E), "s"(O), "v"(a_lo), "v"(e_lo), "v"(a_hi), "v"(e_hi));
         }
+        n += cnt;
+        // position of the last non-zero so far: lane of the highest set bit of either ballot, odd if it is in O
+        const uint32_t top = 63u - (uint32_t)__builtin_clzll(any);
+        last = (uint32_t)(128 * k) + 2u * top + (uint32_t)((O >> top) & 1ull);
     }
     SparseList L;
     L.n = n;
-    L.last = last_hi + 63u - (uint32_t)__builtin_clzll(last_b);
+    L.last = last;
     return L;
 }
 

@@ -222,6 +222,7 @@ __device__ __forceinline__ void load_coeffs(const int lane, float (&c)[CH][16], 
 // so every PCM sample is read from HBM once. The two waves of a stereo clip meet twice per frame (LDS flag
 // hand-shakes, no workgroup barrier: other clips of the workgroup never wait) to assemble and flush the frame.
 constexpr int kPackBytes = kPackRows * 64 * 16;
+constexpr int kPackBytesHot = kPackRowsHot * 64 * 16;   // what lossy_chain2x_kernel keeps in LDS
 struct ClipLds {
     WaveLds<1> wl[2];
     __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 128];
@@ -716,9 +717,10 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
 // row (window, twiddles, band tables) is read from LDS once per frame for both channels, the PCM comes in as float2
 // loads (both channels of a sample-frame), and the two channels are two independent dependency chains inside one
 // instruction stream, so a wait on LDS is shared by twice the work. Same device functions, same bytes as the other forms.
+constexpr uint32_t kListOff = 2736;   // item list of the list-form packer: [trash][sentinel][kListCap entries] = 2056 bytes
 struct Clip2xLds {
     StereoLds wl;
-    __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 256];
+    __attribute__((aligned(16))) uint8_t stage[kListOff + 8 + 4 * kListCap + 8];   // 4800 >= kFrameCap + 64 + 2 * 64 (general form's trash bytes)
     __attribute__((aligned(16))) uint32_t qh[2][512];
     uint16_t sfwh[2][32];
     uint32_t runtab[kRunTabEntries];
@@ -729,6 +731,7 @@ struct Clip2xLds {
     uint32_t pad[3];
 };
 static_assert(sizeof(Clip2xLds) % 16 == 0, "clip LDS block keeps 16-byte alignment");
+static_assert(kListOff + 8 + 4 * kListCap + 8 >= kFrameCap + 64 + 128, "staging buffer holds the largest frame and the general form's trash bytes");
 
 #ifndef FLO_C2X_THREADS
 #define FLO_C2X_THREADS 768
@@ -748,9 +751,9 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
     const int lane = tid & 63;
     {
         float4 *dstp = reinterpret_cast<float4 *>(lds_raw);
-        for (int i = tid; i < kPackRows * 64; i += (int)blockDim.x) dstp[i] = A.T.pack[i];
+        for (int i = tid; i < kPackRowsHot * 64; i += (int)blockDim.x) dstp[i] = A.T.pack[i];
         for (int i = tid; i < clips_per_wg; i += (int)blockDim.x) {
-            Clip2xLds &c0 = *reinterpret_cast<Clip2xLds *>(lds_raw + kPackBytes + (size_t)i * sizeof(Clip2xLds));
+            Clip2xLds &c0 = *reinterpret_cast<Clip2xLds *>(lds_raw + kPackBytesHot + (size_t)i * sizeof(Clip2xLds));
             c0.ready[0] = 0;
             c0.ready[1] = 0;
             c0.consumed = 0;
@@ -762,12 +765,18 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
     // waves 0 .. g-1 are the transform waves (one per SIMD first), waves g .. 2g-1 the packers
     const int cl = wv % clips_per_wg;
     const int w = wv < clips_per_wg ? 0 : 2;
-    Clip2xLds &cs = *reinterpret_cast<Clip2xLds *>(lds_raw + kPackBytes + (size_t)cl * sizeof(Clip2xLds));
+    Clip2xLds &cs = *reinterpret_cast<Clip2xLds *>(lds_raw + kPackBytesHot + (size_t)cl * sizeof(Clip2xLds));
     // Clips are dealt dynamically: the workgroups are persistent (one per CU, the LDS holds no second one) and every
     // (transform wave, packer wave) pair takes the next unclaimed clip of the batch when it has finished one, so CUs
     // stay full until the batch runs out whatever the clip lengths. The packer claims (one atomic per clip) and tells
     // its transform wave through LDS; frame counters run on across clips (fbase), so nothing is ever reset.
     uint32_t fbase = 0, seq = 0;
+#ifdef FLO_PRIO_P
+    if (w == 2) __builtin_amdgcn_s_setprio(FLO_PRIO_P);
+#endif
+#ifdef FLO_PRIO_T
+    if (w != 2) __builtin_amdgcn_s_setprio(FLO_PRIO_T);
+#endif
     for (;;) {
     unsigned clip;
     if (w == 2) {
@@ -805,17 +814,20 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             wait_counter(&cs.ready[0], fbase + h + 1);
             wait_counter(&cs.ready[1], fbase + h + 1);
             STAMP(0);
-            // hand-over buffer of a channel: value 16 l + k sits at halfword 8 l + k (k < 8) or 512 + 8 l + k - 8.
-            // Strided view for the ballot form: x[e] = value at position 64 e + lane.
-            uint32_t x[2][16], xs[2][8];
-            const uint32_t hw0 = 8u * ((uint32_t)ln >> 4) + ((uint32_t)ln & 7u) + 512u * (((uint32_t)ln >> 3) & 1u);
+#ifdef FLO_STAMPS
+            const unsigned long long st_frame0 = st_last;
+#endif
+            // hand-over buffer of a channel: the 1024 integers in natural order (value p at halfword p). One dword per lane
+            // and 128 positions: xd[k] = positions 128 k + 2 lane and + 1 (what sparse_list_build ranks); xs = the lane's 16
+            // contiguous values (general form only).
+            uint32_t xd[2][8], xs[2][8];
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
-                const uint16_t *hv = reinterpret_cast<const uint16_t *>(cs.qh[ch]);
+                const uint32_t *hv = cs.qh[ch];
 #pragma unroll
-                for (int e = 0; e < 16; e++) x[ch][e] = hv[hw0 + 32u * (uint32_t)e];
+                for (int k = 0; k < 8; k++) xd[ch][k] = hv[64 * k + ln];
                 const uint4 *src = reinterpret_cast<const uint4 *>(cs.qh[ch]);
-                const uint4 x0 = src[ln], x1 = src[64 + ln];   // the lane's 16 contiguous values (general form only)
+                const uint4 x0 = src[2 * ln], x1 = src[2 * ln + 1];
                 xs[ch][0] = x0.x, xs[ch][1] = x0.y, xs[ch][2] = x0.z, xs[ch][3] = x0.w;
                 xs[ch][4] = x1.x, xs[ch][5] = x1.y, xs[ch][6] = x1.z, xs[ch][7] = x1.w;
             }
@@ -823,7 +835,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             set_counter(&cs.consumed, fbase + h + 1);
             STAMP(1);
 #if FLO_ABLATE3 >= 1
-            for (int e = 0; e < 16; e++) { FLO_KEEP(x[0][e]); FLO_KEEP(x[1][e]); }
+            for (int e = 0; e < 8; e++) { FLO_KEEP(xd[0][e]); FLO_KEEP(xd[1][e]); }
             for (int e = 0; e < 8; e++) { FLO_KEEP(xs[0][e]); FLO_KEEP(xs[1][e]); }
             continue;
 #endif
@@ -838,15 +850,15 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             }
             uint32_t tot[2];
             uint32_t pos = 112;   // 12 + 50 * 2: length word of channel 0
-            // the two channels' item lists live in the unused tail of the staging buffer (a frame that takes the list
-            // form is at most 1.7 KB long; the general form only runs when the lists are dead)
-            const uint32_t lst_a[2] = {stage_a + 2048u + 8u, stage_a + 3088u + 8u};
-            SparseList SL[2];
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++) SL[ch] = sparse_list_build(ln, x[ch], lst_a[ch]);
+            // The item list of the channel being packed lives in the tail of the staging buffer, behind anything a frame
+            // made of list-form blobs can reach (a blob of n non-zeros is at most 2 n + 2 * 127 + 11 bytes long); a
+            // channel whose blob could reach the list takes the general form (only behind a dense first channel).
+            const uint32_t lst_a = stage_a + kListOff + 8u;
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
-                uint32_t t = sparse_list_emit(ln, SL[ch], f_a + pos + 4u, tab_a, lst_a[ch]);
+                uint32_t t = kSparseFallback;
+                const SparseList SL = sparse_list_build(ln, xd[ch], lst_a);
+                if (pend + pos + 4u + 2u * SL.n + 265u <= kListOff) t = sparse_list_emit(ln, SL, f_a + pos + 4u, tab_a, lst_a);
                 if (t == kSparseFallback) {   // uniform: dense frame (many runs, a run longer than 255)
                     int q[1][16];
                     uint32_t hi[8];
@@ -893,6 +905,13 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             written += (unsigned long long)n16 << 4;
             wave_sync();
             STAMP(4);
+#ifdef FLO_STAMPS
+            {
+                const unsigned long long busy = st_last - st_frame0;
+                if (busy > 12000) { st_sum[9] += busy; st_sum[10] += 1; }
+                if (busy > 20000) { st_sum[11] += busy; st_sum[12] += 1; }
+            }
+#endif
         }
         if (lane < (int)pend) gout[written + lane] = (uint8_t)tailb;
         if (lane == 0) A.clip_bytes[clip] = written + pend;
@@ -970,10 +989,13 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         band_stats_2<DIRTY>(ln, c, lds, T, energy1, bmax1);
         FLO_MARK("bandstats_done");
         STAMP(4);
+        QuantRows qrows;   // in flight under the masking pass
+        quant_rows_load(ln, T, qrows);
+        __builtin_amdgcn_sched_barrier(0);
         // masking level, temporal step and scale factors of both channels in one pass: channel 0 on lanes 0..24, channel 1
         // on lanes 32..56 (band_stats_2 leaves every band's totals in both halves)
         const int bnd = ln & 31, up = ln >> 5;
-        const float rcount = T.pack[26 * 64 + bnd].z;
+        const float rcount = T.pack[kRowLane * 64 + bnd].z;
         uint32_t sfw1;
         {
             const float a = spread_threshold_2(ln, energy1, rcount, T);
@@ -992,7 +1014,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         FLO_MARK("mask_done");
         STAMP(5);
         uint32_t xs[2][8];
-        quantise_2(ln, c, lds, T, xs);
+        quantise_2(ln, c, lds, T, qrows, xs);
         FLO_MARK("quant_done");
         STAMP(6);
         if (DBG && A.dbg_q) {
@@ -1005,12 +1027,22 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         }
         if (DBG && A.dbg_sfw && bnd < 25) A.dbg_sfw[((frame0 + h) * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
         wait_counter(&cs.consumed, fbase + h);   // the packer has taken the previous frame out of the hand-over buffer
+#ifdef FLO_STAMPS
+        {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long t_;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+            const unsigned long long dt = t_ - st_last;
+            if (dt > 1000) { st_sum[9] += dt; st_sum[10] += 1; }
+            if (dt > 5000) { st_sum[11] += dt; st_sum[12] += 1; }
+        }
+#endif
         STAMP(7);
 #pragma unroll
-        for (int ch = 0; ch < 2; ch++) {
+        for (int ch = 0; ch < 2; ch++) {   // natural order: the lane's 16 integers are 32 contiguous bytes
             uint4 *dq = reinterpret_cast<uint4 *>(cs.qh[ch]);
-            dq[ln] = make_uint4(xs[ch][0], xs[ch][1], xs[ch][2], xs[ch][3]);
-            dq[64 + ln] = make_uint4(xs[ch][4], xs[ch][5], xs[ch][6], xs[ch][7]);
+            dq[2 * ln] = make_uint4(xs[ch][0], xs[ch][1], xs[ch][2], xs[ch][3]);
+            dq[2 * ln + 1] = make_uint4(xs[ch][4], xs[ch][5], xs[ch][6], xs[ch][7]);
         }
         if (bnd < 25) cs.sfwh[up][bnd] = (uint16_t)sfw1;
         set_counter(&cs.ready[0], fbase + h + 1);
@@ -1136,7 +1168,7 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
     float energy1, bmax1;   // channel 0's band b on lane b, channel 1's on lane 32 + b
     band_stats_2(lane, c, lds, T, energy1, bmax1);
     const int bnd = lane & 31, up = lane >> 5;
-    const float rcount = T.pack[26 * 64 + bnd].z;
+    const float rcount = T.pack[kRowLane * 64 + bnd].z;
     const float a = spread_threshold_2(lane, energy1, rcount, T);
     if (PASS == 1) {
         if (bnd < 25) A.a_t[(gframe * 2 + up) * 32 + bnd] = a;
@@ -1154,7 +1186,11 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
     }
     wave_sync();
     uint32_t xs[2][8];
-    quantise_2(lane, c, lds, T, xs);
+    {
+        QuantRows qrows;
+        quant_rows_load(lane, T, qrows);
+        quantise_2(lane, c, lds, T, qrows, xs);
+    }
     if (A.dbg_q) {
 #pragma unroll
         for (int ch = 0; ch < 2; ch++) {
@@ -1425,15 +1461,18 @@ __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigne
     if (w >= n) return;
     const int lane = lane_id();
     const unsigned short *qv = reinterpret_cast<const unsigned short *>(q) + w * 1024;
-    uint32_t x[16];
-#pragma unroll
-    for (int e = 0; e < 16; e++) x[e] = qv[64 * e + lane];
     uint32_t total = kSparseFallback;
     if (form == 0) {
+        uint32_t xd[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) xd[k] = reinterpret_cast<const uint32_t *>(qv)[64 * k + lane];
         const uint32_t lst_a = (uint32_t)(uintptr_t)lst + 8u;
-        const SparseList SL = sparse_list_build(lane, x, lst_a);
+        const SparseList SL = sparse_list_build(lane, xd, lst_a);
         total = sparse_list_emit(lane, SL, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab, lst_a);
     } else if (form == 2) {
+        uint32_t x[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) x[e] = qv[64 * e + lane];
         total = sparse_ballot_pack(lane, x, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab);
     }
     if (total == kSparseFallback) {
@@ -1579,7 +1618,7 @@ static int launch_chain3_t(const LossyArgs &A, hipStream_t s) {
 // clips per workgroup of the two-wave (lock-step stereo) form
 int chain2x_clips_per_wg(int n_clips) {
     int g = (n_clips + 255) / 256;
-    const int gmax = (int)((160 * 1024 - kPackBytes) / sizeof(Clip2xLds));
+    const int gmax = (int)((160 * 1024 - kPackBytesHot) / sizeof(Clip2xLds));
     if (g > gmax) g = gmax;
     if (g > FLO_C2X_THREADS / 128) g = FLO_C2X_THREADS / 128;   // twelve waves: three per SIMD (up to 168 registers each)
     return g < 1 ? 1 : g;
@@ -1591,7 +1630,7 @@ static int launch_chain2x_t(const LossyArgs &A, hipStream_t s) {
         const int v = atoi(e);
         if (v >= 1 && v <= FLO_C2X_THREADS / 128) g = v;
     }
-    const size_t lds = kPackBytes + (size_t)g * sizeof(Clip2xLds);
+    const size_t lds = kPackBytesHot + (size_t)g * sizeof(Clip2xLds);
     if (int rc = allow_big_lds(reinterpret_cast<const void *>(&lossy_chain2x_kernel<COEFFS, DIRTY, DBG>))) return rc;
     unsigned wgs = (unsigned)((A.n_clips + g - 1) / g);
     if (A.n_cus > 0 && wgs > (unsigned)A.n_cus) wgs = (unsigned)A.n_cus;   // persistent: one workgroup per CU, clips dealt dynamically

@@ -2,6 +2,8 @@
 // step by step exactly as the Rust reference does.
 #include "tables.hpp"
 
+#include "pack_rows.h"
+
 #include <cmath>
 #include <cstring>
 
@@ -108,11 +110,11 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
     }
 
     // per-lane constant pack [row][lane][4] (layout documented in lossy_device.hpp)
-    t.pack.assign(46 * 64 * 4, 0.0f);
+    t.pack.assign((size_t)kPackRows * 64 * 4, 0.0f);
     t.pack_ext.assign(2 * 64 * 4, 0.0f);
     auto P = [&](int row, int lane, int i) -> float & { return t.pack[((size_t)row * 64 + lane) * 4 + i]; };
-    // row 45 is not per lane: its first 24 floats are s10d[1..24], read uniformly by every lane
-    for (int d = 1; d < kNumBands; d++) P(45, (d - 1) / 4, (d - 1) % 4) = t.s10d[d];
+    // row kRowS10 is not per lane: its first 24 floats are s10d[1..24], read uniformly by every lane
+    for (int d = 1; d < kNumBands; d++) P(kRowS10, (d - 1) / 4, (d - 1) % 4) = t.s10d[d];
     for (int lane = 0; lane < 64; lane++) {
         for (int r = 0; r < 8; r++) {
             int eo, oo;
@@ -125,22 +127,22 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
                 eo = 2 * i;
                 oo = 1023 - 2 * i;
             }
-            P(r, lane, 0) = t.window[eo];
-            P(r, lane, 1) = t.window[oo];
-            P(r, lane, 2) = t.window[1024 + eo];
-            P(r, lane, 3) = t.window[1024 + oo];
+            P(kRowWin + r, lane, 0) = t.window[eo];
+            P(kRowWin + r, lane, 1) = t.window[oo];
+            P(kRowWin + r, lane, 2) = t.window[1024 + eo];
+            P(kRowWin + r, lane, 3) = t.window[1024 + oo];
             int m = lane + 64 * r;
-            P(8 + (r >> 1), lane, 2 * (r & 1)) = t.twiddle[2 * m];
-            P(8 + (r >> 1), lane, 2 * (r & 1) + 1) = t.twiddle[2 * m + 1];
+            P(kRowTw + (r >> 1), lane, 2 * (r & 1)) = t.twiddle[2 * m];
+            P(kRowTw + (r >> 1), lane, 2 * (r & 1) + 1) = t.twiddle[2 * m + 1];
         }
         for (int k = 1; k < 8; k++) {
             int idx = 2 * (k - 1);  // float index inside the 16-float group
-            P(12 + idx / 4, lane, idx % 4) = t.t1[((k - 1) * 64 + lane) * 2];
-            P(12 + idx / 4, lane, idx % 4 + 1) = t.t1[((k - 1) * 64 + lane) * 2 + 1];
-            P(16 + idx / 4, lane, idx % 4) = t.t2[((k - 1) * 8 + (lane & 7)) * 2];
-            P(16 + idx / 4, lane, idx % 4 + 1) = t.t2[((k - 1) * 8 + (lane & 7)) * 2 + 1];
+            P(kRowF1 + idx / 4, lane, idx % 4) = t.t1[((k - 1) * 64 + lane) * 2];
+            P(kRowF1 + idx / 4, lane, idx % 4 + 1) = t.t1[((k - 1) * 64 + lane) * 2 + 1];
+            P(kRowF2 + idx / 4, lane, idx % 4) = t.t2[((k - 1) * 8 + (lane & 7)) * 2];
+            P(kRowF2 + idx / 4, lane, idx % 4 + 1) = t.t2[((k - 1) * 8 + (lane & 7)) * 2 + 1];
         }
-        for (int e = 0; e < 16; e++) P(20 + e / 4, lane, e % 4) = t.ath_lin[16 * lane + e];
+        for (int e = 0; e < 16; e++) P(kRowAth + e / 4, lane, e % 4) = t.ath_lin[16 * lane + e];
     }
 
     // segments of the contiguous layout (lane j owns k in [16j, 16j+16))
@@ -174,13 +176,9 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
         int n = (int)(t.band_slot0[b + 1] - t.band_slot0[b]);
         if (n > t.max_band_slots) t.max_band_slots = n;
     }
-    // pack rows 24..26: per-lane band bookkeeping, stored as raw 32-bit patterns
+    // per-lane band bookkeeping, stored as raw 32-bit patterns
     auto PU = [&](int row, int lane, int i, uint32_t v) { memcpy(&t.pack[((size_t)row * 64 + lane) * 4 + i], &v, 4); };
     for (int lane = 0; lane < 64; lane++) {
-        for (int i = 0; i < 8; i++) {
-            uint32_t b0 = t.band[16 * lane + 2 * i], b1 = t.band[16 * lane + 2 * i + 1];
-            PU(24 + i / 4, lane, i % 4, (b0 * 8u) | ((b1 * 8u) << 16));  // byte offsets into bandv (float2 per band)
-        }
         const int bl = lane & 31;
         const int b = bl < 25 ? bl : 24;
         const float cnt = t.band_count[b];
@@ -190,21 +188,22 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
         // band b is reduced by lane b (even slots) and lane 32 + b (odd slots)
         const uint32_t bs0 = t.band_slot0[b] + (uint32_t)(lane >> 5);
         const uint32_t bs1 = bl < 25 ? t.band_slot0[b + 1] : 0u;
-        // rows 27..30 byte offsets into bandv (float2 per band); rows 31..34 keep multipliers; rows 35..38 slot destinations
+        // kRowBo: byte offsets into bandv (float2 per band); kRowKeep: restart multipliers; kRowDst: slot destinations
         {
             uint32_t slot = t.lane_slot0[lane];
             for (int e = 0; e < 16; e++) {
                 const bool end = (t.lane_bnd[lane] >> e) & 1u;
-                PU(27 + e / 4, lane, e % 4, (uint32_t)t.band[16 * lane + e] * 8u);
-                P(31 + e / 4, lane, e % 4) = end ? 0.0f : 1.0f;
-                PU(35 + e / 4, lane, e % 4, (end ? slot : (uint32_t)(kSlotCapHost + lane)) * 8u);
+                PU(kRowBo + e / 4, lane, e % 4, (uint32_t)t.band[16 * lane + e] * 8u);
+                P(kRowKeep + e / 4, lane, e % 4) = end ? 0.0f : 1.0f;
+                PU(kRowDst + e / 4, lane, e % 4, (end ? slot : (uint32_t)(kSlotCapHost + lane)) * 8u);
                 if (end) slot++;
             }
         }
-        // rows 39..44: the slots this band lane adds (every other slot of its band), padded with the zero slot
+        // kRowLst (first 12) / kRowLstCold (next 12): the slots this band lane adds (every other slot of its band), padded
+        // with the zero slot
         for (int u = 0; u < 24; u++) {
             const uint32_t sidx = bs0 + 2u * (uint32_t)u;
-            PU(39 + u / 4, lane, u % 4, (sidx < bs1 ? sidx : (uint32_t)(kSlotCapHost + 64)) * 8u);
+            PU((u < 12 ? kRowLst : kRowLstCold - 3) + u / 4, lane, u % 4, (sidx < bs1 ? sidx : (uint32_t)(kSlotCapHost + 64)) * 8u);
         }
         // entries 24..31 (a band can span all 64 lanes: 32 slots per reducer lane) live outside the LDS pack: only the
         // widest band of sample rates from 128 kHz up reaches them, and the kernels read them from global memory
@@ -213,10 +212,10 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
             const uint32_t v = (sidx < bs1 ? sidx : (uint32_t)(kSlotCapHost + 64)) * 8u;
             memcpy(&t.pack_ext[((size_t)((u - 24) / 4) * 64 + lane) * 4 + u % 4], &v, 4);
         }
-        PU(26, lane, 0, t.lane_bnd[lane]);
-        PU(26, lane, 1, t.lane_slot0[lane]);
-        PU(26, lane, 2, rc);
-        PU(26, lane, 3, bs0 | (bs1 << 16));
+        PU(kRowLane, lane, 0, t.lane_bnd[lane]);
+        PU(kRowLane, lane, 1, t.lane_slot0[lane]);
+        PU(kRowLane, lane, 2, rc);
+        PU(kRowLane, lane, 3, bs0 | (bs1 << 16));
     }
 }
 

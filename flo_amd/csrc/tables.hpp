@@ -29,7 +29,7 @@ struct LossyTablesHost {
     std::vector<float> t2;          // [7][8][2]   e^{-2 pi i n*k/64},     k = 1..7
     std::vector<float> ath_db;      // [1024]
     std::vector<float> ath_lin;     // [1024] 10^((smr_thr + fl(ath-10))/20): amplitude below which ATH alone drops
-    std::vector<float> pack;        // [46][64][4] per-lane constant pack (see lossy_device.hpp)
+    std::vector<float> pack;        // [kPackRows][64][4] per-lane constant pack (pack_rows.h)
     std::vector<float> pack_ext;    // [2][64][4] slot-list groups 6 and 7 (bands of more than 48 lane segments: 128 kHz and up)
     std::vector<uint8_t> band;      // [1024]
     std::vector<float> band_count;  // [25]
