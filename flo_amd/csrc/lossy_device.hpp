@@ -1563,6 +1563,135 @@ __device__ __forceinline__ uint32_t sparse_list_emit(const int lane, const Spars
     return tot;
 }
 
+// ------------------------------------------------------------------------------------------------ sparse RLE, block form
+// serialize_sparse (encoder.rs:284-314) from the natural-order hand-over read one dword per lane: xd[k] holds positions
+// 128 k + 2 lane (low half) and + 1 (high half). It is the ballot form above on blocks of 128 positions: two compares
+// per block give the non-zero ballots E (even positions) and O (odd positions), everything that describes the record
+// structure is scalar arithmetic on them (run starts S_lo = E & ~(O << 1 | carry), S_hi = O & ~E; a zero run of 128 or
+// more can only sit in front of a block's FIRST non-zero), and a value's byte offset is
+//   2 (non-zeros + run starts in front of it) + (wide records so far)
+// from eight v_mbcnt. Two facts keep the odd positions free: the value of an odd position always sits exactly two bytes
+// behind where its lane's even position goes (either the even value or the odd value's own record header fills those
+// two bytes), and a lane starts at most one run, whose table slot and rank do not depend on which half starts it.
+// Cost per non-empty block is independent of how many non-zeros it holds: dense frames cost what sparse ones do.
+// Not handled (the caller takes the general form, which rewrites the blob): more runs than the run table holds, a
+// non-zero run longer than 255 (continuation records).
+__device__ __forceinline__ uint32_t sparse_block_pack(const int lane, const uint32_t (&xd)[8], const uint32_t blob, const uint32_t tab) {
+    uint32_t nM = 0, nS = 0, W = 0, cz = 0;   // non-zeros, run starts, wide records so far; zeros since the last non-zero
+    unsigned long long carry = 0;              // bit 0: the position in front of the block is a non-zero
+    const uint32_t tmax = tab + 4u * (uint32_t)(kRunTabEntries - 1);
+    const uint32_t pos_l = (uint32_t)(2 * lane);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t lo = xd[k] & 0xFFFFu, hi = xd[k] >> 16;
+        const unsigned long long E = __ballot(lo != 0u), O = __ballot(hi != 0u);
+        const unsigned long long any = E | O;
+        if (any == 0ull) {   // uniform: 128 zeros
+            cz += 128u;
+            carry = 0;
+            continue;
+        }
+        {   // zeros in front of the block's first non-zero: a two-byte varint shifts everything from here on by one byte
+            const uint32_t fe = E ? 2u * (uint32_t)__builtin_ctzll(E) : 999u, fo = O ? 2u * (uint32_t)__builtin_ctzll(O) + 1u : 999u;
+            const uint32_t f = fe < fo ? fe : fo;
+            W += cz + f >= 128u ? 1u : 0u;
+        }
+        const unsigned long long S_lo = E & ~((O << 1) | carry), S_hi = O & ~E, S = S_lo | S_hi;
+        carry = O >> 63;
+        {
+            const uint32_t top = 63u - (uint32_t)__builtin_clzll(any);
+            cz = 127u - (2u * top + (uint32_t)((O >> top) & 1ull));
+        }
+        const uint32_t nzb = __builtin_amdgcn_mbcnt_hi((uint32_t)(O >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)O, mbcnt64(E)));
+        const uint32_t stb = __builtin_amdgcn_mbcnt_hi((uint32_t)(S_hi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)S_hi, mbcnt64(S_lo)));
+        // byte address of the lane's even-position value: 2 (items in front of it) + blob + W; the header of a run that
+        // starts on the even position is one of those items
+        const uint32_t slo = (uint32_t)((S_lo >> lane) & 1ull);
+        const uint32_t a = ((nzb + stb + slo) << 1) + (blob + W + 2u * (nM + nS));
+        // run table: slot 1 + (runs in front), entry (rank of the run's first non-zero) << 16 | position
+        uint32_t ta = (stb << 2) + (tab + 4u * (nS + 1u));
+        ta = ta < tmax ? ta : tmax;
+        const uint32_t shi = (uint32_t)((S_hi >> lane) & 1ull);
+        const uint32_t ent = ((nzb + nM) << 16) | (pos_l + (uint32_t)(128 * k) + shi);
+        {
+            const uint32_t lo8 = lo >> 8, hi8 = hi >> 8;
+            unsigned long long sv;
+            asm volatile("s_mov_b64 %0, exec\n\t"
+                         "s_mov_b64 exec, %1\n\tds_write_b8 %4, %5\n\tds_write_b8 %4, %6 offset:1\n\t"
+                         "s_mov_b64 exec, %2\n\tds_write_b8 %4, %7 offset:2\n\tds_write_b8 %4, %8 offset:3\n\t"
+                         "s_mov_b64 exec, %3\n\tds_write_b32 %9, %10\n\t"
+                         "s_mov_b64 exec, %0"
+                         : "=&s"(sv)
+                         : "s"(E), "s"(O), "s"(S), "v"(a), "v"(lo), "v"(lo8), "v"(hi), "v"(hi8), "v"(ta), "v"(ent));
+        }
+        nM += (uint32_t)__builtin_popcountll(E) + (uint32_t)__builtin_popcountll(O);
+        nS += (uint32_t)__builtin_popcountll(S);
+    }
+    const uint32_t N = nM, R = nS;
+    if (N == 0u) {   // 1024 zeros: [varint 1024][0] = 80 08 00
+        if (lane == 0) {
+            lds_st8_at(blob, 0x80u, 0);
+            lds_st8_at(blob, 0x08u, 1);
+            lds_st8_at(blob, 0u, 2);
+        }
+        return 3u;
+    }
+    if (R > (uint32_t)(kRunTabEntries - 2)) return kSparseFallback;
+    // sentinels: slot 0 = (position 0, rank 0); slot R + 1 = (rank N)
+    if (lane == 0) {
+        asm volatile("ds_write_b32 %0, %1" ::"v"(tab), "v"(0u) : "memory");
+        asm volatile("ds_write_b32 %0, %1" ::"v"(tab + 4u * (R + 1u)), "v"(N << 16) : "memory");
+    }
+    // header pass: one lane per run
+    uint32_t wdone = 0;   // wide records of the runs handled so far
+    bool too_long = false;
+    for (uint32_t j0 = 0; j0 < R; j0 += 64u) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        const bool act = j < R;
+        const uint32_t ja = tab + 4u * (act ? j : 0u);
+        uint32_t e0, e1, e2;
+        asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:4\n\tds_read_b32 %2, %3 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(e0), "=&v"(e1), "=&v"(e2)
+                     : "v"(ja)
+                     : "memory");
+        const uint32_t p0 = e0 & 0xFFFFu, r0 = e0 >> 16, p1 = e1 & 0xFFFFu, r1 = e1 >> 16, r2 = e2 >> 16;
+        const uint32_t cnt = r2 - r1;
+        const uint32_t zrun = p1 - (p0 + (r1 - r0));
+        const bool wide = act && zrun >= 128u;
+        const unsigned long long wb = __ballot(wide);
+        too_long |= __ballot(act && cnt > 255u) != 0ull;
+        uint32_t wex = wdone;
+        if (wb != 0ull) {   // uniform
+            wex += mbcnt64(wb);
+            wdone += (uint32_t)__builtin_popcountll(wb);
+        }
+        const uint32_t ha = ((r1 + j) << 1) + (blob + wex);
+        if (act) {
+            lds_st8_at(ha, wide ? ((zrun & 0x7Fu) | 0x80u) : zrun, 0);
+            lds_st8_at(ha, wide ? (zrun >> 7) : cnt, 1);
+            if (wide) lds_st8_at(ha, cnt, 2);
+        }
+    }
+    if (too_long) return kSparseFallback;
+    // closing record of a trailing zero run: [varint zeros][0]
+    uint32_t tot = 2u * (N + R) + W;
+    if (cz != 0u) {
+        const uint32_t ta = blob + tot;
+        if (lane == 0) {
+            if (cz >= 128u) {
+                lds_st8_at(ta, (cz & 0x7Fu) | 0x80u, 0);
+                lds_st8_at(ta, cz >> 7, 1);
+                lds_st8_at(ta, 0u, 2);
+            } else {
+                lds_st8_at(ta, cz, 0);
+                lds_st8_at(ta, 0u, 1);
+            }
+        }
+        tot += cz >= 128u ? 3u : 2u;
+    }
+    return tot;
+}
+
 // single channel
 __device__ __forceinline__ void sparse_emit(const int lane, const int (&q)[16], const SparsePlan &P, uint8_t *dst,
                                             uint32_t trash_off) {

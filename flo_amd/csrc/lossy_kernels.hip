@@ -431,6 +431,12 @@ __device__ __forceinline__ void wait_counter(const uint32_t *p, uint32_t want) {
     } while (true);
 }
 // publish: every LDS access this wave issued before is performed first (a wave's LDS instructions execute in order)
+// The counter's value now, through a ds_read the compiler tracks (it waits where the value is first used): issued well
+// ahead of the hand-over, it turns the usual case - the partner is already there - into no wait at all.
+__device__ __forceinline__ uint32_t peek_counter(const uint32_t *p) {
+    typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
+    return *reinterpret_cast<lds_vu32 *>((uintptr_t)(uint32_t)(uintptr_t)p);
+}
 __device__ __forceinline__ void set_counter(uint32_t *p, uint32_t v) {
     const uint32_t a = (uint32_t)(uintptr_t)p;
     asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
@@ -805,14 +811,17 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         uint32_t pend = 0, tailb = 0;
         const uint32_t tab_a = (uint32_t)(uintptr_t)cs.runtab;
         const uint32_t stage_a = (uint32_t)(uintptr_t)cs.stage;
+        uint32_t ready_early = 0;
 #ifdef FLO_STAMPS
         unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
         for (unsigned h = 0; h < hops; h++) {
             const int ln = lane_id_opaque();
-            wait_counter(&cs.ready[0], fbase + h + 1);
-            wait_counter(&cs.ready[1], fbase + h + 1);
+            if (ready_early < fbase + h + 1) {
+                wait_counter(&cs.ready[0], fbase + h + 1);
+                wait_counter(&cs.ready[1], fbase + h + 1);
+            }
             STAMP(0);
 #ifdef FLO_STAMPS
             const unsigned long long st_frame0 = st_last;
@@ -820,23 +829,21 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             // hand-over buffer of a channel: the 1024 integers in natural order (value p at halfword p). One dword per lane
             // and 128 positions: xd[k] = positions 128 k + 2 lane and + 1 (what sparse_list_build ranks); xs = the lane's 16
             // contiguous values (general form only).
-            uint32_t xd[2][8], xs[2][8];
+            uint32_t xd[2][8];
+            // (lanes 32..63 find their dword four further on or back: the transform wave swaps the two 16-byte halves of
+            // every other group of four lanes so that its own 16-byte stores fall on distinct banks)
+            const uint32_t ldw = (uint32_t)ln ^ (((uint32_t)ln >> 3) & 4u);
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
                 const uint32_t *hv = cs.qh[ch];
 #pragma unroll
-                for (int k = 0; k < 8; k++) xd[ch][k] = hv[64 * k + ln];
-                const uint4 *src = reinterpret_cast<const uint4 *>(cs.qh[ch]);
-                const uint4 x0 = src[2 * ln], x1 = src[2 * ln + 1];
-                xs[ch][0] = x0.x, xs[ch][1] = x0.y, xs[ch][2] = x0.z, xs[ch][3] = x0.w;
-                xs[ch][4] = x1.x, xs[ch][5] = x1.y, xs[ch][6] = x1.z, xs[ch][7] = x1.w;
+                for (int k = 0; k < 8; k++) xd[ch][k] = hv[64 * k + ldw];
             }
             const uint32_t sfw_both = cs.sfwh[ln >> 5][ln & 31];   // scale words: lanes 0..24 left, 32..56 right
             set_counter(&cs.consumed, fbase + h + 1);
             STAMP(1);
 #if FLO_ABLATE3 >= 1
             for (int e = 0; e < 8; e++) { FLO_KEEP(xd[0][e]); FLO_KEEP(xd[1][e]); }
-            for (int e = 0; e < 8; e++) { FLO_KEEP(xs[0][e]); FLO_KEEP(xs[1][e]); }
             continue;
 #endif
             // the < 16 bytes the previous frame left unflushed go back to the front of the staging buffer
@@ -850,26 +857,36 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             }
             uint32_t tot[2];
             uint32_t pos = 112;   // 12 + 50 * 2: length word of channel 0
-            // The item list of the channel being packed lives in the tail of the staging buffer, behind anything a frame
-            // made of list-form blobs can reach (a blob of n non-zeros is at most 2 n + 2 * 127 + 11 bytes long); a
-            // channel whose blob could reach the list takes the general form (only behind a dense first channel).
-            const uint32_t lst_a = stage_a + kListOff + 8u;
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
+#ifdef FLO_P_LIST
+                const uint32_t lst_a = stage_a + kListOff + 8u;
                 uint32_t t = kSparseFallback;
                 const SparseList SL = sparse_list_build(ln, xd[ch], lst_a);
                 if (pend + pos + 4u + 2u * SL.n + 265u <= kListOff) t = sparse_list_emit(ln, SL, f_a + pos + 4u, tab_a, lst_a);
+#else
+                uint32_t t = sparse_block_pack(ln, xd[ch], f_a + pos + 4u, tab_a);
+#endif
                 if (t == kSparseFallback) {   // uniform: dense frame (many runs, a run longer than 255)
+                    // the general form wants the lane's 16 contiguous values: one trip through the (still unused) tail of
+                    // the staging buffer re-deals the dwords
+                    uint32_t *scr = reinterpret_cast<uint32_t *>(stage + 2560);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) scr[64 * k + ln] = xd[ch][k];
+                    wave_sync();
+                    const uint4 x0 = reinterpret_cast<const uint4 *>(scr)[2 * ln], x1 = reinterpret_cast<const uint4 *>(scr)[2 * ln + 1];
+                    wave_sync();
+                    const uint32_t xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                     int q[1][16];
                     uint32_t hi[8];
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
-                        hi[k] = xs[ch][k] >> 16;
-                        q[0][2 * k] = (int)xs[ch][k];
+                        hi[k] = xs[k] >> 16;
+                        q[0][2 * k] = (int)xs[k];
                         q[0][2 * k + 1] = (int)hi[k];
                     }
                     SparsePlan P[1];
-                    sparse_plan_m(ln, nonzero_mask16_packed(xs[ch], hi), P[0]);
+                    sparse_plan_m(ln, nonzero_mask16_packed(xs, hi), P[0]);
                     uint8_t *const dsts[1] = {f + pos + 4};
                     // trash bytes of the general form: the tail of the staging buffer, two per lane
                     const uint32_t trash[1] = {(uint32_t)((stage + kFrameCap + 64 + 2 * ln) - dsts[0])};
@@ -895,11 +912,17 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
                 A.frame_size[frame0 + h] = flen;
             }
             wave_sync();
+            // has the transform wave published the next frame meanwhile? (asked before the flush, needed after it)
+            const uint32_t r0 = peek_counter(&cs.ready[0]), r1 = peek_counter(&cs.ready[1]);
             const uint32_t have = pend + flen;
             const uint32_t n16 = have >> 4;
             const uint4 *src = reinterpret_cast<const uint4 *>(stage);
             uint4 *dst = reinterpret_cast<uint4 *>(gout + written);
             for (uint32_t i = ln; i < n16; i += 64) dst[i] = src[i];
+            {
+                const uint32_t a0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0), a1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r1);
+                ready_early = a0 < a1 ? a0 : a1;
+            }
             pend = have & 15u;
             tailb = (ln < (int)pend) ? stage[(n16 << 4) + ln] : 0u;
             written += (unsigned long long)n16 << 4;
@@ -991,6 +1014,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         STAMP(4);
         QuantRows qrows;   // in flight under the masking pass
         quant_rows_load(ln, T, qrows);
+        const uint32_t consumed_early = peek_counter(&cs.consumed);   // the hand-over's usual answer, two phases ahead
         __builtin_amdgcn_sched_barrier(0);
         // masking level, temporal step and scale factors of both channels in one pass: channel 0 on lanes 0..24, channel 1
         // on lanes 32..56 (band_stats_2 leaves every band's totals in both halves)
@@ -1026,7 +1050,8 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             }
         }
         if (DBG && A.dbg_sfw && bnd < 25) A.dbg_sfw[((frame0 + h) * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
-        wait_counter(&cs.consumed, fbase + h);   // the packer has taken the previous frame out of the hand-over buffer
+        // the packer has taken the previous frame out of the hand-over buffer (usually long ago: see consumed_early)
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)consumed_early) < fbase + h) wait_counter(&cs.consumed, fbase + h);
 #ifdef FLO_STAMPS
         {
             __builtin_amdgcn_sched_barrier(0);
@@ -1039,10 +1064,14 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
 #endif
         STAMP(7);
 #pragma unroll
-        for (int ch = 0; ch < 2; ch++) {   // natural order: the lane's 16 integers are 32 contiguous bytes
+        for (int ch = 0; ch < 2; ch++) {
+            // natural order: the lane's 16 integers are 32 contiguous bytes, except that lanes 4..7 of every eight store
+            // their two 16-byte halves the other way round: a 16-byte store instruction then covers all banks with eight
+            // consecutive lanes (at a plain 32-byte stride lanes l and l + 4 would collide); the packer reads accordingly
             uint4 *dq = reinterpret_cast<uint4 *>(cs.qh[ch]);
-            dq[2 * ln] = make_uint4(xs[ch][0], xs[ch][1], xs[ch][2], xs[ch][3]);
-            dq[2 * ln + 1] = make_uint4(xs[ch][4], xs[ch][5], xs[ch][6], xs[ch][7]);
+            const int sw = (ln >> 2) & 1;
+            dq[2 * ln + sw] = make_uint4(xs[ch][0], xs[ch][1], xs[ch][2], xs[ch][3]);
+            dq[2 * ln + (sw ^ 1)] = make_uint4(xs[ch][4], xs[ch][5], xs[ch][6], xs[ch][7]);
         }
         if (bnd < 25) cs.sfwh[up][bnd] = (uint16_t)sfw1;
         set_counter(&cs.ready[0], fbase + h + 1);
@@ -1469,6 +1498,11 @@ __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigne
         const uint32_t lst_a = (uint32_t)(uintptr_t)lst + 8u;
         const SparseList SL = sparse_list_build(lane, xd, lst_a);
         total = sparse_list_emit(lane, SL, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab, lst_a);
+    } else if (form == 3) {
+        uint32_t xd[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) xd[k] = reinterpret_cast<const uint32_t *>(qv)[64 * k + lane];
+        total = sparse_block_pack(lane, xd, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab);
     } else if (form == 2) {
         uint32_t x[16];
 #pragma unroll

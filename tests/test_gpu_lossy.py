@@ -55,7 +55,7 @@ def _patterns():
     return np.array(pats)
 
 
-@pytest.mark.parametrize("form", [0, 1, 2], ids=["encoder", "general", "ballot"])
+@pytest.mark.parametrize("form", [0, 1, 2, 3], ids=["encoder", "general", "ballot", "block"])
 def test_sparse_pack_bit_exact(ctx, form):
     # form 0 = the packer as every encode runs it (list form, the general form behind it for dense vectors)
     pats = _patterns()
@@ -113,12 +113,13 @@ def test_sparse_pack_ballot_form_on_structured_vectors(ctx):
         a = np.zeros(1024, np.int16); a[:k] = 3; a[k + 200:k + 203] = 4; pats.append(a)      # wide record starts item k
         b = np.zeros(1024, np.int16); b[:k - 1] = 3; b[k + 200:k + 203] = 4; pats.append(b)
     pats = np.array(pats)
-    got0, got1, got2 = ctx.sparse_pack(pats, 0), ctx.sparse_pack(pats, 1), ctx.sparse_pack(pats, 2)
+    got0, got1, got2, got3 = (ctx.sparse_pack(pats, f) for f in (0, 1, 2, 3))
     for i, p in enumerate(pats):
         ref = O.serialize_sparse(p)
         assert got0[i] == ref, i
         assert got1[i] == ref, i
         assert got2[i] == ref, i
+        assert got3[i] == ref, i
 
 
 @pytest.mark.parametrize("exact", [False, True], ids=["shipped", "exact"])
