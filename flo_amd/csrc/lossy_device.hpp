@@ -894,8 +894,7 @@ struct StereoLds {
         float4 xch4[kXch4];
         float2 coef2[kCoef2];
         struct {
-            float2 sum[kSlots];   // per lane segment: (sum c^2 left, right) | 64 trash slots | zero slot
-            float2 mx[kSlots];    //                   (max |c| left, right)
+            float4 slot[kSlots];  // per lane segment: (sum c^2 left, right, max |c| left, right) | 64 trash slots | zero slot
             float4 ts[32];        // per band: amplitude thresholds (left, right), scale factors (left, right)
         } a;
     } u;
@@ -911,28 +910,31 @@ struct StereoLds {
 template <uint32_t DIRTY = 0xFFFFu>
 __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16], StereoLds &L, const LossyDevTables &T,
                                              float &energy1, float &bmax1) {
-    // Slot addresses as 32-bit LDS offsets from ONE scalar base: as the sum of the clip's LDS base and the member offset
-    // the compiler re-added both terms for every access (two vector adds per slot instead of one). The accesses go
-    // through address-space-3 pointers so that they stay ds_* instructions.
-    typedef __attribute__((address_space(3))) v2f lds_v2f;
-    const uint32_t sum0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)L.u.a.sum);
-    const uint32_t mxd = (uint32_t)(reinterpret_cast<char *>(L.u.a.mx) - reinterpret_cast<char *>(L.u.a.sum));
-    {   // the zero slot shares storage with the exchange buffer: written every frame (by every lane: no branch)
-        const uint32_t z = sum0 + 8u * (uint32_t)kZeroSlot;
-        *reinterpret_cast<lds_v2f *>((uintptr_t)z) = splat2(0.f);
-        *reinterpret_cast<lds_v2f *>((uintptr_t)(z + mxd)) = splat2(0.f);
+    // Slot addresses as 32-bit LDS offsets from ONE scalar base (as the sum of the clip's LDS base and the member offset
+    // the compiler re-added both terms for every access); the accesses go through address-space-3 pointers so that they
+    // stay ds_* instructions. A slot is 16 bytes (sums of both channels, maxima of both channels): ONE ds_write_b128 per
+    // stored element and ONE ds_read_b128 (4 LDS cycles) per gathered slot - a two-address ds_read2_b64 takes 8. The
+    // table rows hold 8-byte-slot offsets (shared with band_stats<CH>), hence the factor 2.
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4f lds_v4f;
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)L.u.a.slot);
+    // the zero slot shares storage with the exchange buffer: written every frame (lane l writes dword l & 3: no branch, one
+    // register of zeros, a 4-byte store instead of a 16-byte one)
+    {
+        typedef __attribute__((address_space(3))) float lds_f32;
+        float z = 0.f;
+        asm volatile("" : "+v"(z));   // not a loop invariant: four registers of zeros held across the frame loop were spilled
+        *reinterpret_cast<lds_f32 *>((uintptr_t)(s0 + 16u * (uint32_t)kZeroSlot + 4u * ((uint32_t)lane & 3u))) = z;
     }
     uint32_t so[12];
-#ifndef FLO_BS_LATE_LISTS
 #pragma unroll
     for (int g = 0; g < 3; g++) {
         const float4 lst = T.pack[(kRowLst + g) * 64 + lane];
-        so[4 * g + 0] = sum0 + __float_as_uint(lst.x), so[4 * g + 1] = sum0 + __float_as_uint(lst.y);
-        so[4 * g + 2] = sum0 + __float_as_uint(lst.z), so[4 * g + 3] = sum0 + __float_as_uint(lst.w);
+        so[4 * g + 0] = s0 + 2u * __float_as_uint(lst.x), so[4 * g + 1] = s0 + 2u * __float_as_uint(lst.y);
+        so[4 * g + 2] = s0 + 2u * __float_as_uint(lst.z), so[4 * g + 3] = s0 + 2u * __float_as_uint(lst.w);
     }
-#endif
     const uint32_t dirty = DIRTY;   // compile-time: straight-line code
-    v2f acc = splat2(0.f), mx = splat2(0.f);
+    v4f am = {0.f, 0.f, 0.f, 0.f};   // running (sum left, sum right, max left, max right): one register quad, stored as it is
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const float4 keep = T.pack[(kRowKeep + g) * 64 + lane];
@@ -942,61 +944,44 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int e = 4 * g + k;
-            acc = fma2(c[e], c[e], acc);
-            mx.x = max_abs_raw(mx.x, c[e].x);
-            mx.y = max_abs_raw(mx.y, c[e].y);
+            am.xy = fma2(c[e], c[e], am.xy);
+            am.z = max_abs_raw(am.z, c[e].x);
+            am.w = max_abs_raw(am.w, c[e].y);
             if ((dirty >> e) & 1u) {   // compile-time
-                const uint32_t a = sum0 + dv[k];
-                *reinterpret_cast<lds_v2f *>((uintptr_t)a) = acc;
-                *reinterpret_cast<lds_v2f *>((uintptr_t)(a + mxd)) = mx;
+                *reinterpret_cast<lds_v4f *>((uintptr_t)(s0 + 2u * dv[k])) = am;
                 if (e < 15) {
-                    acc = acc * splat2(kp[k]);
-                    mx = mx * splat2(kp[k]);
+                    am.xy = am.xy * splat2(kp[k]);
+                    am.zw = am.zw * splat2(kp[k]);
                 }
             }
         }
     }
-#ifdef FLO_BS_LATE_LISTS
-#pragma unroll
-    for (int g = 0; g < 3; g++) {
-        const float4 lst = T.pack[(kRowLst + g) * 64 + lane];
-        so[4 * g + 0] = sum0 + __float_as_uint(lst.x), so[4 * g + 1] = sum0 + __float_as_uint(lst.y);
-        so[4 * g + 2] = sum0 + __float_as_uint(lst.z), so[4 * g + 3] = sum0 + __float_as_uint(lst.w);
-    }
-#endif
     wave_sync();
     v2f energy = splat2(0.f), bmax = splat2(0.f);
 #pragma unroll
     for (int g = 0; g < 3; g++) {   // four slots in flight at a time: twelve would not fit the register budget
-        v2f vs[4], vm[4];
+        v4f v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const lds_v4f *>((uintptr_t)so[4 * g + u]);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            vs[u] = *reinterpret_cast<const lds_v2f *>((uintptr_t)so[4 * g + u]);
-            vm[u] = *reinterpret_cast<const lds_v2f *>((uintptr_t)(so[4 * g + u] + mxd));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            energy = energy + vs[u];
-            bmax.x = max_raw(bmax.x, vm[u].x);
-            bmax.y = max_raw(bmax.y, vm[u].y);
+            energy = energy + (v2f){v[u].x, v[u].y};
+            bmax.x = max_raw(bmax.x, v[u].z);
+            bmax.y = max_raw(bmax.y, v[u].w);
         }
     }
     const int groups = (T.max_band_slots + 7) >> 3;
     for (int g = 3; g < groups; g++) {
         const float4 lst = g < 6 ? T.pack_g[(kRowLstCold + g - 3) * 64 + lane] : T.pack_ext[(g - 6) * 64 + lane];
         const uint32_t sx[4] = {__float_as_uint(lst.x), __float_as_uint(lst.y), __float_as_uint(lst.z), __float_as_uint(lst.w)};
-        v2f ws[4], wm[4];
+        v4f w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) w[u] = *reinterpret_cast<const lds_v4f *>((uintptr_t)(s0 + 2u * sx[u]));
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t a = sum0 + sx[u];
-            ws[u] = *reinterpret_cast<const lds_v2f *>((uintptr_t)a);
-            wm[u] = *reinterpret_cast<const lds_v2f *>((uintptr_t)(a + mxd));
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            energy = energy + ws[u];
-            bmax.x = max_raw(bmax.x, wm[u].x);
-            bmax.y = max_raw(bmax.y, wm[u].y);
+            energy = energy + (v2f){w[u].x, w[u].y};
+            bmax.x = max_raw(bmax.x, w[u].z);
+            bmax.y = max_raw(bmax.y, w[u].w);
         }
     }
     // lanes b / 32 + b hold the even-slot / odd-slot halves of band b for both channels. After the swap the first result
@@ -1010,12 +995,6 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
     wave_sync();
 }
 
-// quantise (shipped form: amplitude-domain keep test) for both channels, four coefficients at a time; the integers
-// leave as i16 pairs, element 2k in the low half of xs[ch][k] (the hand-over format of the packer wave).
-// Per coefficient and channel: sign-matched pred(0.5) by one bit-field insert, one truncating convert, the threshold
-// maximum, one compare and one select; the select of an odd element writes the upper half of the even element's
-// register directly (SDWA), so nothing is spent on packing. (threshold, scale) of a coefficient's band come from ONE
-// 16-byte gather. Same arithmetic as quantise<., false>: bit-identical integers.
 // The band-offset rows of the quantiser (what its gathers wait for). The chain kernel fetches them BEFORE the masking
 // pass, whose long dependent chain then hides their latency.
 struct QuantRows {
