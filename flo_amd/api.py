@@ -210,8 +210,8 @@ class Context:
         return dict(q=q, sf_words=sfw)
 
     def sparse_pack(self, q, form=0):
-        """serialize_sparse on the device. form 0: as the encoder packs (list form, general form for dense vectors);
-        form 1: the general form for every vector; form 2: the ballot form first."""
+        """serialize_sparse on the device. form 0: as the encoder packs (block form, general form for dense vectors);
+        form 1: the general form for every vector."""
         q = np.ascontiguousarray(q, np.int16).reshape(-1, 1024)
         n = q.shape[0]
         out = np.zeros(n * 2080, np.uint8)

@@ -1120,7 +1120,7 @@ extern "C" int flo_lossy_quantize(flo_ctx *c, const float *coeffs, size_t num_ho
 
 extern "C" int flo_sparse_pack(flo_ctx *c, const int16_t *q, size_t n_vec, int form, uint8_t *out, size_t out_cap,
                                uint32_t *out_off) {
-    if (!c || (n_vec && (!q || !out || !out_off)) || form < 0 || form > 3) return FLO_ERR_ARG;
+    if (!c || (n_vec && (!q || !out || !out_off)) || form < 0 || form > 1) return FLO_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (out_off) out_off[0] = 0;
     if (!n_vec) return FLO_OK;

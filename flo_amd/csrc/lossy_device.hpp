@@ -1229,24 +1229,7 @@ __device__ __forceinline__ void sparse_emit_n(const int lane, const int (&q)[CH]
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------ sparse RLE, ballot form
-// The same serialize_sparse (encoder.rs:284-314) for the sparse frames that make up nearly all of a q <= 0.8 encode
-// (about 60 of 1024 values non-zero, 20 records), at a quarter of the vector instructions of the form above.
-//
-// Layout: lane l holds x[e] = value at position 64 e + l (zero-extended u16), so ONE compare per register gives 64
-// consecutive bits of the non-zero mask in a scalar register pair. Everything that describes the record structure is
-// then computed on the scalar unit from those sixteen ballots (run starts S = M & ~(M << 1), counts by s_bcnt1, the
-// first non-zero of a word by s_ff1): it costs no vector issue slots. What is left for the vector unit:
-//   value pass   per non-empty word: the value's byte offset = 2 (non-zeros before it + run starts at or before it)
-//                + (wide records so far) is four v_mbcnt with the word's ballots and one add-shift; active lanes store
-//                their two bytes. The run-start lanes also scatter (position, rank) into a small run table (LDS).
-//   header pass  one lane per RUN (64 at a time) reads its neighbours from the run table: zero run = gap to the previous
-//                run's end, count = difference of ranks, and stores [varint zero_run][count] in front of the run's values.
-// A zero run of 128 or more (two varint bytes) can only sit in front of the FIRST run start of a 64-bit word (runs of
-// zeros inside a word are shorter than 64), so the extra byte it inserts shifts a whole word's values uniformly: it is
-// a scalar term of the word's base address, and the header pass counts such records with one ballot.
-// Not handled here (the caller then takes the general form above, which overwrites whatever was written): a non-zero
-// run longer than 255 (continuation records), more runs than the run table holds. Both only occur in dense frames.
+// ------------------------------------------------------------------------------------------------ sparse RLE, block form
 constexpr int kRunTabEntries = 128;   // slot 0 and slot R + 1 are sentinels: up to 126 runs
 constexpr uint32_t kSparseFallback = 0xFFFFFFFFu;
 
@@ -1256,296 +1239,14 @@ __device__ __forceinline__ void lds_st8_at(uint32_t a, uint32_t v, const int off
     else if (off == 2) asm volatile("ds_write_b8 %0, %1 offset:2" ::"v"(a), "v"(v) : "memory");
     else asm volatile("ds_write_b8 %0, %1 offset:3" ::"v"(a), "v"(v) : "memory");
 }
-// ds_write_b32 executed by the lanes of `mask` only (a wave-uniform mask, all lanes active on entry): the run-start
-// lanes are known as a scalar bit mask, and testing "my bit" on the vector unit would cost three instructions a word.
-__device__ __forceinline__ void lds_st32_lanes(unsigned long long mask, uint32_t a, uint32_t v) {
-    unsigned long long sv;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
-                 : "=&s"(sv)
-                 : "s"(mask), "v"(a), "v"(v)
-                 : "memory");
-}
-
-// two byte stores (lo at a + OFF, hi at a + OFF + 1) executed by the lanes of `mask` only
-template <int OFF>
-__device__ __forceinline__ void lds_st8x2_lanes(unsigned long long mask, uint32_t a, uint32_t lo, uint32_t hi) {
-    unsigned long long sv;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b8 %2, %3 offset:%5\n\tds_write_b8 %2, %4 offset:%6\n\ts_mov_b64 exec, %0"
-                 : "=&s"(sv)
-                 : "s"(mask), "v"(a), "v"(lo), "v"(hi), "n"(OFF), "n"(OFF + 1)
-                 : "memory");
-}
-
-// blob: LDS byte address of the channel's first sparse byte; tab: LDS byte address of kRunTabEntries dwords.
-// Returns the blob's length, or kSparseFallback.
-__device__ __forceinline__ uint32_t sparse_ballot_pack(const int lane, const uint32_t (&x)[16], const uint32_t blob,
-                                                       const uint32_t tab) {
-    uint32_t nM = 0, nS = 0, W = 0, cz = 0;   // non-zeros, run starts, wide records so far; zeros since the last non-zero
-    unsigned long long prevbit = 0;
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        // the word's ballot is made where it is used: sixteen live register pairs would push scalars into spills
-        const unsigned long long b = __ballot(x[e] != 0u);
-        if (b == 0ull) {   // uniform
-            cz += 64u;
-            prevbit = 0;
-            continue;
-        }
-        const uint32_t f = (uint32_t)__builtin_ctzll(b);
-        {
-            const uint32_t t7 = (cz + f) >> 7;   // zeros in front of the word's first run, in units of 128 (at most 8)
-            W += t7 < 1u ? t7 : 1u;
-        }
-        const unsigned long long S = b & ~((b << 1) | prevbit);
-        prevbit = b >> 63;
-        cz = (uint32_t)__builtin_clzll(b);
-        const uint32_t s0 = (uint32_t)S & 1u;
-        const unsigned long long U = S >> 1;
-        // v2 = non-zeros of this word below the lane; v4 - v2 = run starts of this word in lanes 1..lane
-        const uint32_t v2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-        const uint32_t v4 = __builtin_amdgcn_mbcnt_hi((uint32_t)(U >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)U, v2));
-        const uint32_t H = blob + W;
-        const uint32_t K = nM + nS + s0 + (H >> 1);
-        // byte address of the lane's value: 2 (items in front of it) + H; the odd bit of H is or-ed in on the vector
-        // side (one instruction) rather than chosen by a scalar branch over two store variants (a dozen)
-        const uint32_t a = ((v4 + K) << 1) | (H & 1u);
-        // run table: slot = (runs before this word) + (starts of this word at or before the lane), slot 0 is a sentinel
-        const uint32_t sp = v4 - v2;
-        uint32_t ta = (sp << 2) + (tab + 4u * (nS + s0));
-        const uint32_t tmax = tab + 4u * (uint32_t)(kRunTabEntries - 1);
-        ta = ta < tmax ? ta : tmax;
-        const uint32_t ent = ((v2 << 16) + ((nM << 16) | (uint32_t)(64 * e))) | (uint32_t)lane;
-        {
-            // value bytes by the non-zero lanes, table entries by the run-start lanes: one save / restore of exec
-            const uint32_t hi = x[e] >> 8;
-            unsigned long long sv;
-            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b8 %3, %4\n\tds_write_b8 %3, %5 offset:1\n\t"
-                         "s_mov_b64 exec, %2\n\tds_write_b32 %6, %7\n\ts_mov_b64 exec, %0"
-                         : "=&s"(sv)
-                         : "s"(b), "s"(S), "v"(a), "v"(x[e]), "v"(hi), "v"(ta), "v"(ent)
-                         : "memory");
-        }
-        nM += (uint32_t)__builtin_popcountll(b);
-        nS += (uint32_t)__builtin_popcountll(S);
-    }
-    const uint32_t N = nM, R = nS;
-    if (R > (uint32_t)(kRunTabEntries - 2)) return kSparseFallback;
-    // sentinels: slot 0 = (position 0, rank 0); slot R + 1 = (rank N)
-    if (lane == 0) {
-        asm volatile("ds_write_b32 %0, %1" ::"v"(tab), "v"(0u) : "memory");
-        asm volatile("ds_write_b32 %0, %1" ::"v"(tab + 4u * (R + 1u)), "v"(N << 16) : "memory");
-    }
-    // header pass: one lane per run
-    uint32_t wdone = 0;   // wide records of the runs handled so far
-    bool too_long = false;
-    for (uint32_t j0 = 0; j0 < R; j0 += 64u) {
-        const uint32_t j = j0 + (uint32_t)lane;
-        const bool act = j < R;
-        const uint32_t ja = tab + 4u * (act ? j : 0u);
-        uint32_t e0, e1, e2;
-        asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:4\n\tds_read_b32 %2, %3 offset:8\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(e0), "=&v"(e1), "=&v"(e2)
-                     : "v"(ja)
-                     : "memory");
-        const uint32_t p0 = e0 & 0xFFFFu, r0 = e0 >> 16, p1 = e1 & 0xFFFFu, r1 = e1 >> 16, r2 = e2 >> 16;
-        const uint32_t cnt = r2 - r1;
-        const uint32_t zrun = p1 - (p0 + (r1 - r0));
-        const bool wide = act && zrun >= 128u;
-        const unsigned long long wb = __ballot(wide);
-        too_long |= __ballot(act && cnt > 255u) != 0ull;
-        uint32_t wex = wdone;
-        if (wb != 0ull) {   // uniform
-            wex += __builtin_amdgcn_mbcnt_hi((uint32_t)(wb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wb, 0u));
-            wdone += (uint32_t)__builtin_popcountll(wb);
-        }
-        const uint32_t ha = ((r1 + j) << 1) + (blob + wex);
-        if (act) {
-            lds_st8_at(ha, wide ? ((zrun & 0x7Fu) | 0x80u) : zrun, 0);
-            lds_st8_at(ha, wide ? (zrun >> 7) : cnt, 1);
-            if (wide) lds_st8_at(ha, cnt, 2);
-        }
-    }
-    if (too_long) return kSparseFallback;
-    // closing record of a trailing zero run: [varint zeros][0]  (cz = zeros behind the last non-zero, 1024 if none)
-    uint32_t tot = 2u * (N + R) + W;
-    if (cz != 0u) {
-        const uint32_t ta = blob + tot;
-        if (lane == 0) {
-            if (cz >= 128u) {
-                lds_st8_at(ta, (cz & 0x7Fu) | 0x80u, 0);
-                lds_st8_at(ta, cz >> 7, 1);
-                lds_st8_at(ta, 0u, 2);
-            } else {
-                lds_st8_at(ta, cz, 0);
-                lds_st8_at(ta, 0u, 1);
-            }
-        }
-        tot += cz >= 128u ? 3u : 2u;
-    }
-    return tot;
-}
-
-// ------------------------------------------------------------------------------------------------ sparse RLE, list form
-// serialize_sparse (encoder.rs:284-314) for sparse frames, item-stationary: what nearly every frame of a q <= 0.8
-// encode looks like is about 60 non-zeros in 20 runs spread over 7 of the 16 ballot words, so the work is done per
-// NON-ZERO instead of per word position.
-//   build   per non-empty word of the strided view (x[e] = value at position 64 e + lane): one compare gives the word's
-//           ballot, two v_mbcnt the rank of each non-zero, and the non-zero lanes append (position << 16 | value) to a
-//           list in LDS. The only scalar state carried from word to word is the count.
-//   emit    lane i takes list item i (64 at a time): its predecessor's position tells whether it starts a run and how
-//           long the zero run in front of it is; ballots of "starts" and of "starts behind 128 zeros or more" (two-byte
-//           varint) give, through v_mbcnt, the byte offset 2 (items + records so far) + (wide records so far). The lane
-//           stores its value, a start lane also its zero-run varint and a run-table entry (offset of its count byte,
-//           rank); then one lane per RUN takes the count as the difference of neighbouring ranks.
-// Not handled (the caller takes the general form, which rewrites the blob): more than kListCap non-zeros, more runs
-// than the run table holds, a run longer than 255 (continuation records). All of them are dense frames.
-// LDS scratch: tab = kRunTabEntries dwords; lst = kListCap dwords with TWO more dwords in front of it (lst - 8: the
-// inactive lanes' store target, lst - 4: the "position -1" sentinel).
-constexpr int kListCap = 512;
-
 __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
-__device__ __forceinline__ void lds_st8_any(uint32_t a, uint32_t v) {
-    asm volatile("ds_write_b8 %0, %1" ::"v"(a), "v"(v));
-}
-__device__ __forceinline__ void lds_st8_any1(uint32_t a, uint32_t v) {
-    asm volatile("ds_write_b8 %0, %1 offset:1" ::"v"(a), "v"(v));
-}
-__device__ __forceinline__ void lds_st32_any(uint32_t a, uint32_t v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v));
-}
 
-struct SparseList {
-    uint32_t n;       // non-zeros (uniform); more than kListCap: the list is incomplete
-    uint32_t last;    // position of the last non-zero (valid when n > 0)
-};
-
-// xd[k] (k = 0..7): the dword that holds positions 128 k + 2 lane (low half) and + 1 (high half), i.e. the hand-over
-// buffer in natural order read one dword per lane: lanes 0..31 cover one 64-position word, lanes 32..63 the next.
-// The non-zero ballots of the low and of the high halves together rank every non-zero in position order:
-//   rank(lane, low) = non-zeros of both ballots below the lane (four v_mbcnt), rank(lane, high) = that + (low != 0).
-// Once more than kListCap non-zeros have been counted nothing more is stored (the caller falls back).
-__device__ __forceinline__ SparseList sparse_list_build(const int lane, const uint32_t (&xd)[8], const uint32_t lst) {
-    uint32_t n = 0, last = 0;
-    const uint32_t pos0 = (uint32_t)(2 * lane) << 16;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const uint32_t lo = xd[k] & 0xFFFFu, hi = xd[k] >> 16;
-        const unsigned long long E = __ballot(lo != 0u), O = __ballot(hi != 0u);
-        const unsigned long long any = E | O;
-        if (any == 0ull) continue;   // uniform: 128 zeros
-        const uint32_t cnt = (uint32_t)__builtin_popcountll(E) + (uint32_t)__builtin_popcountll(O);
-        if (n + cnt <= (uint32_t)kListCap) {   // uniform
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(O >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)O, mbcnt64(E)));
-            const uint32_t a_lo = (below << 2) + (lst + 4u * n);
-            const uint32_t a_hi = a_lo + (lo != 0u ? 4u : 0u);
-            const uint32_t pk = pos0 + ((uint32_t)(128 * k) << 16);
-            const uint32_t e_lo = lo | pk, e_hi = hi | (pk + 0x10000u);
-            unsigned long long sv;
-            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %3, %4\n\t"
-                         "s_mov_b64 exec, %2\n\tds_write_b32 %5, %6\n\ts_mov_b64 exec, %0"
-                         : "=&s"(sv)
-                         : "s"(E), "s"(O), "v"(a_lo), "v"(e_lo), "v"(a_hi), "v"(e_hi));
-        }
-        n += cnt;
-        // position of the last non-zero so far: lane of the highest set bit of either ballot, odd if it is in O
-        const uint32_t top = 63u - (uint32_t)__builtin_clzll(any);
-        last = (uint32_t)(128 * k) + 2u * top + (uint32_t)((O >> top) & 1ull);
-    }
-    SparseList L;
-    L.n = n;
-    L.last = last;
-    return L;
-}
-
-// blob: LDS byte address of the channel's first sparse byte. Returns the blob's length, or kSparseFallback.
-__device__ __forceinline__ uint32_t sparse_list_emit(const int lane, const SparseList L, const uint32_t blob, const uint32_t tab,
-                                                     const uint32_t lst) {
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    const uint32_t N = L.n;
-    if (N > (uint32_t)kListCap) return kSparseFallback;
-    if (N == 0u) {   // 1024 zeros: [varint 1024][0] = 80 08 00
-        if (lane == 0) {
-            lds_st8_at(blob, 0x80u, 0);
-            lds_st8_at(blob, 0x08u, 1);
-            lds_st8_at(blob, 0u, 2);
-        }
-        return 3u;
-    }
-    const uint32_t trash = lst - 8u;
-    if (lane == 0) lds_st32_any(lst - 4u, 0xFFFF0000u);
-    wave_sync();
-    uint32_t Rb = 0, Wb = 0;
-    const uint32_t tmax = tab + 4u * (uint32_t)(kRunTabEntries - 1);
-    for (uint32_t g0 = 0; g0 < N; g0 += 64u) {
-        const uint32_t g = g0 + (uint32_t)lane;
-        const bool act = g < N;
-        const uint32_t la = lst + 4u * (act ? g : 0u);
-        const uint32_t tprev = *reinterpret_cast<const lds_u32 *>((uintptr_t)(la - 4u));
-        const uint32_t ent = *reinterpret_cast<const lds_u32 *>((uintptr_t)la);
-        const int p = (int)(ent >> 16), pprev = (int)tprev >> 16;
-        const uint32_t zrun = (uint32_t)(p - pprev - 1);
-        const bool start = act && (zrun != 0u || g == 0u);
-        const bool wide = start && zrun >= 128u;
-        const unsigned long long SB = __ballot(start), WB = __ballot(wide);
-        const uint32_t r_excl = Rb + mbcnt64(SB);
-        uint32_t w_incl = Wb;
-        if (WB != 0ull) w_incl += mbcnt64(WB) + (wide ? 1u : 0u);   // uniform
-        const uint32_t off_v = ((g + r_excl + (start ? 1u : 0u)) << 1) + w_incl;   // relative to the blob
-        const uint32_t av = act ? blob + off_v : trash;
-        lds_st8_any(av, ent);
-        lds_st8_any1(av, ent >> 8);
-        // record header in front of a start lane's value: [varint zero_run][count]; the count byte is filled in below
-        const uint32_t ah = start ? blob + off_v - 2u - (wide ? 1u : 0u) : trash;
-        lds_st8_any(ah, wide ? ((zrun & 0x7Fu) | 0x80u) : zrun);
-        if (WB != 0ull) lds_st8_any1(wide ? ah : trash, zrun >> 7);   // uniform
-        uint32_t ta = tab + 4u * r_excl;
-        ta = ta < tmax ? ta : tmax;
-        lds_st32_any(start ? ta : trash, ((off_v - 1u) << 16) | g);
-        Rb += (uint32_t)__builtin_popcountll(SB);
-        Wb += (uint32_t)__builtin_popcountll(WB);
-    }
-    const uint32_t R = Rb, W = Wb;
-    if (R > (uint32_t)(kRunTabEntries - 1)) return kSparseFallback;
-    if (lane == 0) lds_st32_any(tab + 4u * R, N);   // sentinel: rank N
-    wave_sync();
-    bool too_long = false;
-    for (uint32_t j0 = 0; j0 < R; j0 += 64u) {
-        const uint32_t j = j0 + (uint32_t)lane;
-        const bool act = j < R;
-        const uint32_t ja = tab + 4u * (act ? j : 0u);
-        const uint32_t t0 = *reinterpret_cast<const lds_u32 *>((uintptr_t)ja);
-        const uint32_t t1 = *reinterpret_cast<const lds_u32 *>((uintptr_t)(ja + 4u));
-        const uint32_t cnt = (t1 & 0xFFFFu) - (t0 & 0xFFFFu);
-        too_long |= __ballot(act && cnt > 255u) != 0ull;
-        lds_st8_any(act ? blob + (t0 >> 16) : trash, cnt);
-    }
-    if (too_long) return kSparseFallback;
-    // closing record of a trailing zero run: [varint zeros][0]
-    uint32_t tot = 2u * (N + R) + W;
-    const uint32_t cz = 1023u - L.last;
-    if (cz != 0u) {
-        const uint32_t ta = blob + tot;
-        if (lane == 0) {
-            if (cz >= 128u) {
-                lds_st8_at(ta, (cz & 0x7Fu) | 0x80u, 0);
-                lds_st8_at(ta, cz >> 7, 1);
-                lds_st8_at(ta, 0u, 2);
-            } else {
-                lds_st8_at(ta, cz, 0);
-                lds_st8_at(ta, 0u, 1);
-            }
-        }
-        tot += cz >= 128u ? 3u : 2u;
-    }
-    return tot;
-}
-
-// ------------------------------------------------------------------------------------------------ sparse RLE, block form
 // serialize_sparse (encoder.rs:284-314) from the natural-order hand-over read one dword per lane: xd[k] holds positions
-// 128 k + 2 lane (low half) and + 1 (high half). It is the ballot form above on blocks of 128 positions: two compares
-// per block give the non-zero ballots E (even positions) and O (odd positions), everything that describes the record
+// 128 k + 2 lane (low half) and + 1 (high half). The record structure of the sparse frames that make up nearly all of a
+// q <= 0.8 encode (about 60 of 1024 values non-zero, 20 records) is computed in the BALLOT domain: two compares per
+// block of 128 positions give the non-zero ballots E (even positions) and O (odd positions), everything that describes the record
 // structure is scalar arithmetic on them (run starts S_lo = E & ~(O << 1 | carry), S_hi = O & ~E; a zero run of 128 or
 // more can only sit in front of a block's FIRST non-zero), and a value's byte offset is
 //   2 (non-zeros + run starts in front of it) + (wide records so far)

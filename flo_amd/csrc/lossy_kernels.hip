@@ -411,7 +411,7 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
 struct Clip3Lds {
     WaveLds<1> wl[2];
     __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 256];
-    __attribute__((aligned(16))) uint32_t qh[2][512];   // [channel][half * 64 + lane] uint4: eight i16 pairs... two uint4 per lane
+    __attribute__((aligned(16))) uint32_t qh[2][512];   // [channel]: the 1024 integers of a frame in natural order
     uint16_t sfwh[2][32];
     uint32_t runtab[kRunTabEntries];   // run table of the ballot-form packer (one channel at a time)
     uint32_t ready[2];      // frames published by channel wave w
@@ -552,24 +552,24 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
             const int ln = lane_id_opaque();
             wait_counter(&cs.ready[0], h + 1);
             wait_counter(&cs.ready[1], h + 1);
-            // hand-over buffer of a channel: value 16 l + k sits at halfword 8 l + k (k < 8) or 512 + 8 l + k - 8.
-            // Strided view for the ballot form: x[e] = value at position 64 e + lane.
-            uint32_t x[2][16], xs[2][8], sfw[2];
-            const uint32_t hw0 = 8u * ((uint32_t)ln >> 4) + ((uint32_t)ln & 7u) + 512u * (((uint32_t)ln >> 3) & 1u);
+            // hand-over buffer of a channel: the 1024 integers in natural order (value p at halfword p). xd[k] = the dword
+            // with positions 128 k + 2 lane and + 1 (what the block-form packer takes); xs = the lane's 16 contiguous values
+            // (general form only)
+            uint32_t xd[2][8], xs[2][8], sfw[2];
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
-                const uint16_t *hv = reinterpret_cast<const uint16_t *>(cs.qh[ch]);
+                const uint32_t *hv = cs.qh[ch];
 #pragma unroll
-                for (int e = 0; e < 16; e++) x[ch][e] = hv[hw0 + 32u * (uint32_t)e];
+                for (int k = 0; k < 8; k++) xd[ch][k] = hv[64 * k + ln];
                 const uint4 *src = reinterpret_cast<const uint4 *>(cs.qh[ch]);
-                const uint4 x0 = src[ln], x1 = src[64 + ln];   // the lane's 16 contiguous values (general form only)
+                const uint4 x0 = src[2 * ln], x1 = src[2 * ln + 1];
                 xs[ch][0] = x0.x, xs[ch][1] = x0.y, xs[ch][2] = x0.z, xs[ch][3] = x0.w;
                 xs[ch][4] = x1.x, xs[ch][5] = x1.y, xs[ch][6] = x1.z, xs[ch][7] = x1.w;
                 sfw[ch] = cs.sfwh[ch][ln & 31];
             }
             set_counter(&cs.consumed, h + 1);
 #if FLO_ABLATE3 >= 1
-            for (int e = 0; e < 16; e++) { FLO_KEEP(x[0][e]); FLO_KEEP(x[1][e]); }
+            for (int e = 0; e < 8; e++) { FLO_KEEP(xd[0][e]); FLO_KEEP(xd[1][e]); }
             for (int e = 0; e < 8; e++) { FLO_KEEP(xs[0][e]); FLO_KEEP(xs[1][e]); }
             continue;
 #endif
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
             uint32_t pos = 112;   // 12 + 50 * 2: length word of channel 0
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
-                uint32_t t = sparse_ballot_pack(ln, x[ch], f_a + pos + 4u, tab_a);
+                uint32_t t = sparse_block_pack(ln, xd[ch], f_a + pos + 4u, tab_a);
                 if (t == kSparseFallback) {   // uniform: dense frame (a run longer than 255, or more than 126 runs)
                     int q[1][16];
                     uint32_t hi[8];
@@ -706,9 +706,9 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
 #pragma unroll
         for (int k = 0; k < 8; k++) xs[k] = __builtin_amdgcn_perm((uint32_t)q[0][2 * k + 1], (uint32_t)q[0][2 * k], 0x05040100u);
         wait_counter(&cs.consumed, h);   // the packer has taken frame h - 1 out of the hand-over buffer
-        uint4 *dq = reinterpret_cast<uint4 *>(cs.qh[w]);
-        dq[ln] = make_uint4(xs[0], xs[1], xs[2], xs[3]);
-        dq[64 + ln] = make_uint4(xs[4], xs[5], xs[6], xs[7]);
+        uint4 *dq = reinterpret_cast<uint4 *>(cs.qh[w]);   // natural order: the lane's 16 integers are 32 contiguous bytes
+        dq[2 * ln] = make_uint4(xs[0], xs[1], xs[2], xs[3]);
+        dq[2 * ln + 1] = make_uint4(xs[4], xs[5], xs[6], xs[7]);
         if (ln < 25) cs.sfwh[w][ln] = (uint16_t)sfw[0];
         set_counter(&cs.ready[w], h + 1);
     };
@@ -723,10 +723,9 @@ __global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clip
 // row (window, twiddles, band tables) is read from LDS once per frame for both channels, the PCM comes in as float2
 // loads (both channels of a sample-frame), and the two channels are two independent dependency chains inside one
 // instruction stream, so a wait on LDS is shared by twice the work. Same device functions, same bytes as the other forms.
-constexpr uint32_t kListOff = 2736;   // item list of the list-form packer: [trash][sentinel][kListCap entries] = 2056 bytes
 struct Clip2xLds {
     StereoLds wl;
-    __attribute__((aligned(16))) uint8_t stage[kListOff + 8 + 4 * kListCap + 8];   // 4800 >= kFrameCap + 64 + 2 * 64 (general form's trash bytes)
+    __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 256];
     __attribute__((aligned(16))) uint32_t qh[2][512];
     uint16_t sfwh[2][32];
     uint32_t runtab[kRunTabEntries];
@@ -737,7 +736,6 @@ struct Clip2xLds {
     uint32_t pad[3];
 };
 static_assert(sizeof(Clip2xLds) % 16 == 0, "clip LDS block keeps 16-byte alignment");
-static_assert(kListOff + 8 + 4 * kListCap + 8 >= kFrameCap + 64 + 128, "staging buffer holds the largest frame and the general form's trash bytes");
 
 #ifndef FLO_C2X_THREADS
 #define FLO_C2X_THREADS 768
@@ -810,7 +808,6 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         unsigned long long written = 0;
         uint32_t pend = 0, tailb = 0;
         const uint32_t tab_a = (uint32_t)(uintptr_t)cs.runtab;
-        const uint32_t stage_a = (uint32_t)(uintptr_t)cs.stage;
         uint32_t ready_early = 0;
 #ifdef FLO_STAMPS
         unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
@@ -859,14 +856,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             uint32_t pos = 112;   // 12 + 50 * 2: length word of channel 0
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
-#ifdef FLO_P_LIST
-                const uint32_t lst_a = stage_a + kListOff + 8u;
-                uint32_t t = kSparseFallback;
-                const SparseList SL = sparse_list_build(ln, xd[ch], lst_a);
-                if (pend + pos + 4u + 2u * SL.n + 265u <= kListOff) t = sparse_list_emit(ln, SL, f_a + pos + 4u, tab_a, lst_a);
-#else
                 uint32_t t = sparse_block_pack(ln, xd[ch], f_a + pos + 4u, tab_a);
-#endif
                 if (t == kSparseFallback) {   // uniform: dense frame (many runs, a run longer than 255)
                     // the general form wants the lane's 16 contiguous values: one trip through the (still unused) tail of
                     // the staging buffer re-deals the dwords
@@ -1230,21 +1220,20 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
     }
     if (A.dbg_sfw && bnd < 25) A.dbg_sfw[(gframe * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
 
-    // ---- packing: the ballot form wants value 64 e + lane in register e: one trip through LDS re-deals the integers
+    // ---- packing: the block form wants the dword with positions 128 k + 2 lane, + 1 in register k: one trip through LDS
+    // re-deals the integers
 #pragma unroll
     for (int ch = 0; ch < 2; ch++) {
         uint4 *dq = reinterpret_cast<uint4 *>(qh[ch]);
-        dq[lane] = make_uint4(xs[ch][0], xs[ch][1], xs[ch][2], xs[ch][3]);
-        dq[64 + lane] = make_uint4(xs[ch][4], xs[ch][5], xs[ch][6], xs[ch][7]);
+        dq[2 * lane] = make_uint4(xs[ch][0], xs[ch][1], xs[ch][2], xs[ch][3]);
+        dq[2 * lane + 1] = make_uint4(xs[ch][4], xs[ch][5], xs[ch][6], xs[ch][7]);
     }
     wave_sync();
-    uint32_t x[2][16];
-    const uint32_t hw0 = 8u * ((uint32_t)lane >> 4) + ((uint32_t)lane & 7u) + 512u * (((uint32_t)lane >> 3) & 1u);
+    uint32_t xd[2][8];
 #pragma unroll
     for (int ch = 0; ch < 2; ch++) {
-        const uint16_t *hv = reinterpret_cast<const uint16_t *>(qh[ch]);
 #pragma unroll
-        for (int e = 0; e < 16; e++) x[ch][e] = hv[hw0 + 32u * (uint32_t)e];
+        for (int k = 0; k < 8; k++) xd[ch][k] = qh[ch][64 * k + lane];
     }
     uint8_t *f = stage;
     const uint32_t f_a = (uint32_t)(uintptr_t)f, tab_a = (uint32_t)(uintptr_t)runtab;
@@ -1256,7 +1245,7 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
     uint32_t pos = 112;   // 12 + 50 * 2: length word of channel 0
 #pragma unroll
     for (int ch = 0; ch < 2; ch++) {
-        uint32_t t = sparse_ballot_pack(lane, x[ch], f_a + pos + 4u, tab_a);
+        uint32_t t = sparse_block_pack(lane, xd[ch], f_a + pos + 4u, tab_a);
         if (t == kSparseFallback) {   // uniform: dense frame (a run longer than 255, or more than 126 runs)
             int q[1][16];
             uint32_t hi16[8];
@@ -1479,13 +1468,12 @@ __global__ __launch_bounds__(64) void mdct_only_kernel(LossyDevTables T, const f
 }
 
 // serialize_sparse of independent 1024-value vectors into fixed slots (flo_sparse_pack): the packer wave's own
-// routine, i.e. the list form with the general form behind it for the vectors it declines. form = 1 forces the
-// general form for every vector, form = 2 takes the ballot form first (tests compare the three).
+// routine, i.e. the block form with the general form behind it for the vectors it declines. form = 1 forces the
+// general form for every vector (tests compare the two).
 __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigned long long n, uint8_t *slots,
                                                          uint32_t *sizes, int form) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[2080 + 128];
     __shared__ uint32_t runtab[kRunTabEntries];
-    __shared__ uint32_t lst[kListCap + 2];
     const unsigned long long w = blockIdx.x;
     if (w >= n) return;
     const int lane = lane_id();
@@ -1495,19 +1483,7 @@ __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigne
         uint32_t xd[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) xd[k] = reinterpret_cast<const uint32_t *>(qv)[64 * k + lane];
-        const uint32_t lst_a = (uint32_t)(uintptr_t)lst + 8u;
-        const SparseList SL = sparse_list_build(lane, xd, lst_a);
-        total = sparse_list_emit(lane, SL, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab, lst_a);
-    } else if (form == 3) {
-        uint32_t xd[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) xd[k] = reinterpret_cast<const uint32_t *>(qv)[64 * k + lane];
         total = sparse_block_pack(lane, xd, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab);
-    } else if (form == 2) {
-        uint32_t x[16];
-#pragma unroll
-        for (int e = 0; e < 16; e++) x[e] = qv[64 * e + lane];
-        total = sparse_ballot_pack(lane, x, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab);
     }
     if (total == kSparseFallback) {
         int v[16];

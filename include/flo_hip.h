@@ -243,9 +243,8 @@ int flo_lossy_analyze(flo_ctx *ctx, const float *pcm, size_t n_interleaved, uint
 int flo_lossy_quantize(flo_ctx *ctx, const float *coeffs, size_t num_hops, uint32_t sample_rate, uint8_t channels,
                        float quality, int exact, int16_t *quantized, uint16_t *sf_words);
 /* serialize_sparse on device: n_vec vectors of 1024 i16 -> bytes; out_off[n_vec+1] prefix offsets.
- * Replaces lossy/encoder.rs:284-314. form = 0: the packer as the encoder runs it (list form for sparse vectors, the
- * general form for the dense ones it declines); form = 1: the general form for every vector; form = 2: the ballot
- * form first (tests compare the three). */
+ * Replaces lossy/encoder.rs:284-314. form = 0: the packer as the encoder runs it (block form for sparse vectors, the
+ * general form for the dense ones it declines); form = 1: the general form for every vector (tests compare the two). */
 int flo_sparse_pack(flo_ctx *ctx, const int16_t *q, size_t n_vec, int form, uint8_t *out, size_t out_cap,
                     uint32_t *out_off);
 

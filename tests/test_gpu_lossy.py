@@ -55,17 +55,17 @@ def _patterns():
     return np.array(pats)
 
 
-@pytest.mark.parametrize("form", [0, 1, 2, 3], ids=["encoder", "general", "ballot", "block"])
+@pytest.mark.parametrize("form", [0, 1], ids=["encoder", "general"])
 def test_sparse_pack_bit_exact(ctx, form):
-    # form 0 = the packer as every encode runs it (list form, the general form behind it for dense vectors)
+    # form 0 = the packer as every encode runs it (block form, the general form behind it for dense vectors)
     pats = _patterns()
     got = ctx.sparse_pack(pats, form)
     for i, p in enumerate(pats):
         assert got[i] == O.serialize_sparse(p), i
 
 
-def test_sparse_pack_ballot_form_on_structured_vectors(ctx):
-    # what the ballot form has to get right: zero runs of 127 / 128 / 129 and longer in front of a word's first run
+def test_sparse_pack_block_form_on_structured_vectors(ctx):
+    # what the block form has to get right: zero runs of 127 / 128 / 129 and longer in front of a word's first run
     # (two-byte varints shift everything behind them by one byte), runs that cross 64-bit word boundaries, runs of
     # exactly 255 and 256, up to 126 and 127 runs (run table capacity), trailing zero runs of every varint size
     rng = np.random.default_rng(5)
@@ -103,8 +103,8 @@ def test_sparse_pack_ballot_form_on_structured_vectors(ctx):
         for _ in range(40):
             keep = rng.uniform(size=1024) < dens * np.exp(-np.arange(1024) / rng.uniform(100, 900))   # low-pass like a spectrum
             pats.append((rng.integers(-32768, 32768, 1024) * keep).astype(np.int16))
-    # the list form's own limits: exactly 255 / 256 / 257 non-zeros, 127 / 128 runs, items whose runs straddle the
-    # 64-item passes, a two-byte varint in front of item 64 and 128
+    # run-table limits (126 / 127 / 128 runs), runs of 255 / 256 / 257 behind wide gaps, records that straddle the
+    # 128-position blocks and the 64-run header passes
     for n in (63, 64, 65, 127, 128, 129, 255, 256, 257):
         a = np.zeros(1024, np.int16); a[:2 * n:2][:n] = 5; pats.append(a)                    # n runs of one
         b = np.zeros(1024, np.int16); b[100:100 + n] = -9; b[900] = 1; pats.append(b)        # one run of n, a wide gap
@@ -113,13 +113,11 @@ def test_sparse_pack_ballot_form_on_structured_vectors(ctx):
         a = np.zeros(1024, np.int16); a[:k] = 3; a[k + 200:k + 203] = 4; pats.append(a)      # wide record starts item k
         b = np.zeros(1024, np.int16); b[:k - 1] = 3; b[k + 200:k + 203] = 4; pats.append(b)
     pats = np.array(pats)
-    got0, got1, got2, got3 = (ctx.sparse_pack(pats, f) for f in (0, 1, 2, 3))
+    got0, got1 = ctx.sparse_pack(pats, 0), ctx.sparse_pack(pats, 1)
     for i, p in enumerate(pats):
         ref = O.serialize_sparse(p)
         assert got0[i] == ref, i
         assert got1[i] == ref, i
-        assert got2[i] == ref, i
-        assert got3[i] == ref, i
 
 
 @pytest.mark.parametrize("exact", [False, True], ids=["shipped", "exact"])
