@@ -142,10 +142,63 @@ def main():
             gather_error = gather_error or "the RCCL communicator of flo_dist_create failed on another rank"
             print(f"[bench] exchange step disabled: {gather_error}", file=sys.stderr)
 
-    def step():
+    exchange_check = None
+    if gather is not None:
+        # Before anything is timed: one small job (8 clips per rank, 3 steps) through the same communicator, checked end to
+        # end - every rank's files as the root received them against a CRC the rank computed from its own fetch(). A
+        # watchdog turns a hung exchange (a protocol bug would block in RCCL for ever) into a failed run with a message.
+        import threading
+        import zlib
+
+        def _hung():
+            print("[bench] exchange self-check hung for 180 s: aborting", file=sys.stderr, flush=True)
+            os._exit(3)
+        wd = threading.Timer(180.0, _hung)
+        wd.daemon = True
+        wd.start()
+        try:
+            small = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [n_il // 10] * 8, sr, ch, args.quality)
+            small.fill_synthetic(seed=0xF10A0D10, clip_id0=50_000_000 + rank * 8)
+            for _ in range(3):
+                small.encode(args.path)
+                small.sync()
+                gather.submit(small)
+            gather.flush()
+            mine = [small.fetch(i) for i in range(8)]
+            crc = torch.tensor([zlib.crc32(b"".join(mine)), sum(len(f) for f in mine)], dtype=torch.int64, device=f"cuda:{local_rank}")
+            crcs = torch.zeros(2 * world, dtype=torch.int64, device=f"cuda:{local_rank}")
+            dist.all_gather_into_tensor(crcs, crc)
+            if rank == 0:
+                import ctypes
+                hip = ctypes.CDLL("libamdhip64.so")
+                hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+                base, offs, sizes = gather.result()
+                torch.cuda.synchronize()
+                ok = True
+                for r in range(world):
+                    n_r = int(sizes[r])
+                    raw = (ctypes.c_uint8 * max(n_r, 1))()
+                    ok = ok and hip.hipMemcpy(raw, base + int(offs[r]), n_r, 2) == 0
+                    blob, pos, files = bytes(raw[:n_r]), 0, []
+                    while pos + 70 <= len(blob) and blob[pos:pos + 4] == b"FLO!":
+                        n = 70 + int.from_bytes(blob[pos + 38:pos + 46], "little") + int.from_bytes(blob[pos + 46:pos + 54], "little")
+                        files.append(blob[pos:pos + n])
+                        pos += (n + 15) & ~15
+                    ok = ok and len(files) == 8 and zlib.crc32(b"".join(files)) == int(crcs[2 * r]) and sum(map(len, files)) == int(crcs[2 * r + 1])
+                exchange_check = ("every rank's files arrived byte for byte (8 clips per rank, 3 steps, CRC32 against the rank's own fetch)"
+                                  if ok else "MISMATCH: gathered files differ from what the ranks encoded")
+                if not ok:
+                    print("[bench] exchange self-check FAILED: gathered files differ from what the ranks encoded", file=sys.stderr)
+            small.close()
+        except Exception as e:   # noqa: BLE001 - the self-check must never take the timed run down with it
+            exchange_check = f"self-check raised {type(e).__name__}: {e}"
+            print(f"[bench] {exchange_check}", file=sys.stderr)
+        wd.cancel()
+
+    def step(with_gather=True):
         batch.encode(args.path)
         batch.sync()
-        if gather is not None:
+        if gather is not None and with_gather:
             gather.submit(batch)
 
     def barrier():
@@ -158,6 +211,18 @@ def main():
         step()
     if gather is not None:
         gather.flush()
+    encode_only_dt = None
+    if gather is not None:
+        # the same K steps without the exchange: what the GPUs do when nothing is gathered (never `value`)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(False)
+        barrier()
+        encode_only_dt = time.perf_counter() - t0
+        t = torch.tensor([encode_only_dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        encode_only_dt = float(t.item())
     ctx.profile_reset()
     ctx.profile_enable(True)
     barrier()
@@ -182,6 +247,10 @@ def main():
             kname, k_ms, k_n = cand, ms, n
             break
     data_bytes = batch.data_bytes()
+    gathered = None
+    if gather is not None and rank == 0:
+        _, g_offs, g_sizes = gather.result()
+        gathered = [int(x) for x in g_sizes]
 
     if rank != 0:
         if dist is not None:
@@ -218,6 +287,28 @@ def main():
             "compressed_bytes_per_gpu": data_bytes,
         },
     }
+    if world > 1:
+        ex = {"reserved_cus": int(os.environ.get("FLO_RESERVE_CUS", "8")) if gather is not None else 0,
+              "self_check": exchange_check}
+        if gather is not None and encode_only_dt is not None:
+            enc_ms = encode_only_dt / args.steps * 1e3
+            into_root = sum(gathered[r] for r in range(world) if r != 0)
+            link_gbs = 77.0     # one xGMI link per direction, nominal (each peer has ONE link to the root)
+            t_link_ms = max(gathered[r] for r in range(world) if r != 0) / (link_gbs * 1e9) * 1e3
+            ex.update({
+                "encode_only": {"value": round(total_samples / args.steps * args.steps / encode_only_dt / 1e6, 1), "unit": "Msamples/s",
+                                "ms_per_step": round(enc_ms, 4), "note": "the same K steps without flo_dist_gather_submit"},
+                "with_gather_ms_per_step": round(dt / args.steps * 1e3, 4),
+                "gather_cost_ms_per_step": round((dt - encode_only_dt) / args.steps * 1e3, 4),
+                "bytes_per_rank_per_step": gathered,
+                "bytes_into_root_per_step": into_root,
+                "achieved_GBs_into_root": round(into_root / (dt / args.steps) / 1e9, 2),
+                "bound": {"per_link_GBs_nominal": link_gbs, "slowest_peer_transfer_ms_at_link_peak": round(t_link_ms, 3),
+                          "overlapped_efficiency_bound": round(min(1.0, enc_ms / max(enc_ms, t_link_ms)), 4),
+                          "note": "weak-scaling efficiency cannot exceed encode / max(encode, transfer): every peer's files cross ONE "
+                                  "xGMI link into the root; the value above is measured, this is the ceiling at nominal link rate"},
+            })
+        out["exchange_detail"] = ex
     if k_n:
         per_launch_s = k_ms / k_n / 1e3
         traffic, traffic_src = hbm_traffic(kname, args.clips_per_gpu, args.clip_seconds)
@@ -298,8 +389,11 @@ def main():
         # the drop-in calls on HOST buffers (what encode_to_flo / Encoder::encode bind to): pageable PCM in, malloc'ed
         # .flo files out, PCIe both ways included. Never `value`: the resident-batch rate above is the kernel's.
         import numpy as np
-        from oracle import oracle as O      # only the synthetic-signal generator (shared integer-exact definition)
-        clips = [O.synth_clip(n_sf, ch, 0xF10A0D10, i) for i in range(64)]
+        # the 64 input clips: the product's own device generator (include/flo_synth.h) + one copy back to the host
+        bg = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [n_il] * 64, sr, ch, args.quality)
+        bg.fill_synthetic(seed=0xF10A0D10, clip_id0=0)
+        clips = [bg.download_pcm(i) for i in range(64)]
+        bg.close()
         for _ in range(3):
             ctx.encode_lossy(clips[0], sr, ch, args.quality)
         t6 = time.perf_counter()

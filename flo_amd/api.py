@@ -111,6 +111,10 @@ class Context:
     def force_path(self, which: int):
         self._chk(self._L.flo_ctx_force_path(self._h, which))
 
+    def reserve_cus(self, n: int):
+        """compute units the persistent encode kernels leave free (for RCCL's kernels when ranks exchange files)"""
+        self._chk(self._L.flo_ctx_reserve_cus(self._h, n))
+
     # -- one clip ---------------------------------------------------------------------------------------
     def encode_lossy(self, samples, sample_rate, channels, quality, metadata=b"") -> bytes:
         p = _f32(samples)
@@ -270,6 +274,20 @@ class Batch:
 
     def fill_synthetic(self, seed=0xF10A0D10, clip_id0=0):
         self.ctx._chk(self._L.flo_batch_fill_synthetic(self._h, seed, clip_id0))
+
+    def download_pcm(self, clip):
+        """the clip's interleaved f32 PCM as it sits in the batch (after upload or fill_synthetic), as a numpy array"""
+        import numpy as np
+        self.sync()
+        n = int(self.n_interleaved[clip])
+        out = np.empty(n, np.float32)
+        if n:
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            rc = hip.hipMemcpy(out.ctypes.data, self.clip_device_ptr(clip), n * 4, 2)
+            if rc != 0:
+                raise FloError(f"hipMemcpy (device to host) failed with {rc}")
+        return out
 
     def encode(self, which=0):
         self.ctx._chk(self._L.flo_batch_encode(self._h, which))

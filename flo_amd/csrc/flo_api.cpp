@@ -18,6 +18,7 @@
 #include "container_kernels.hpp"
 #include "decode_kernels.hpp"
 #include "devpool.hpp"
+#include "dist_engine.hpp"
 #include "stager.hpp"
 #include "lossless_kernels.hpp"
 #include "lossy_kernels.hpp"
@@ -54,7 +55,9 @@ struct flo_ctx {
     hipDeviceProp_t prop{};
     Stager *stager = nullptr;   // pinned staging ring + copy threads of the host-buffer entry points (made on first use)
     hipStream_t up_stream = nullptr, down_stream = nullptr;   // uploads / downloads of flo_encode_batch's pipeline
+    int reserve_cus = -1;   // compute units the persistent chain kernel leaves free (-1: not set; see flo_ctx_reserve_cus)
 };
+static const int kDefaultReservedCus = 8;
 
 static thread_local std::string g_create_err;
 
@@ -111,6 +114,10 @@ extern "C" int flo_ctx_create(int device, flo_ctx **out) {
     {
         std::string serr;
         c->stager = stager_create(serr);   // light: pinned buffers and copy threads appear when first needed
+    }
+    if (const char *e2 = getenv("FLO_RESERVE_CUS")) {   // compute units left to other kernels (RCCL's, at N > 1)
+        const int v = atoi(e2);
+        if (v >= 0 && v < c->prop.multiProcessorCount) c->reserve_cus = v;
     }
     restore();
     *out = c;
@@ -574,7 +581,7 @@ static LossyArgs make_args(flo_batch *b) {
     A.exact = b->exact;
     A.dbg_stamps = b->d_stamps;
     A.next_clip = b->d_next;
-    A.n_cus = b->ctx->prop.multiProcessorCount;
+    A.n_cus = b->ctx->prop.multiProcessorCount - (b->ctx->reserve_cus > 0 ? b->ctx->reserve_cus : 0);
     return A;
 }
 
@@ -1603,36 +1610,126 @@ extern "C" int flo_decode_lossless_i32(flo_ctx *c, const uint8_t *flo, size_t le
 // transfer of step k overlaps the encode of step k + 1. No host synchronisation sits on that path: the sizes of step k
 // travel to pinned host memory asynchronously and are only read when step k + 1 is submitted (by then they have long
 // arrived), which is when the transfers of step k are posted; flo_dist_gather_flush posts and awaits the last ones.
-struct flo_dist {
+// The ordering logic (slot parity, deferred posting, buffer growth) is the DistEngine template of dist_engine.hpp; here it
+// is bound to HIP streams and RCCL. tests/native/dist_engine_test.cpp runs the same template over sockets with several
+// ranks on the CPU.
+#define NCCLRC(ctx, expr)                                                                               \
+    do {                                                                                                \
+        ncclResult_t r_ = (expr);                                                                       \
+        if (r_ != ncclSuccess) return fail(ctx, FLO_ERR_DEVICE, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+
+struct RcclBackend {
+    struct Buffer {
+        uint8_t *p = nullptr;
+        size_t cap = 0;
+    };
     flo_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
-    int rank = 0, world = 1, root = 0;
+    int world = 1;
     hipStream_t cs = nullptr;                 // communication stream
-    // per slot (step parity)
-    uint8_t *send[2] = {nullptr, nullptr};
-    size_t send_cap[2] = {0, 0};
-    uint64_t send_bytes[2] = {0, 0};
-    uint8_t *recv[2] = {nullptr, nullptr};    // root only
-    size_t recv_cap[2] = {0, 0};
     uint64_t *d_sizes[2] = {nullptr, nullptr};   // [world] device
     uint64_t *h_sizes[2] = {nullptr, nullptr};   // [world] pinned host
     uint64_t *h_mine[2] = {nullptr, nullptr};    // pinned host: this rank's packed size
     uint64_t *d_mine[2] = {nullptr, nullptr};
     hipEvent_t ev_packed[2] = {nullptr, nullptr}, ev_sizes[2] = {nullptr, nullptr}, ev_moved[2] = {nullptr, nullptr};
-    bool posted[2] = {true, true};            // the slot's transfers have been posted (nothing pending)
-    bool used[2] = {false, false};
-    uint64_t submits = 0;
     std::vector<uint64_t> pack_off;           // scratch: per-clip offsets of the last pack
-    // result of the most recently completed step (root)
-    std::vector<uint64_t> res_off, res_size;
-    int res_slot = -1;
+
+    // (re)allocate a device buffer to hold `need` bytes; growing waits for the work that may still use the old one
+    int reserve(Buffer &b, size_t need) {
+        if (b.cap >= need) return FLO_OK;
+        flo_ctx *c = ctx;
+        HIPCHK(c, hipStreamSynchronize(cs));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (b.p) HIPCHK(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+        const size_t want = need + need / 4 + 4096;
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) return fail(c, FLO_ERR_NOMEM, std::string("gather buffer: ") + hipGetErrorString(e));
+        b.cap = want;
+        return FLO_OK;
+    }
+    int payload_bytes(void *batch, uint64_t *need) {
+        flo_batch *b = (flo_batch *)batch;
+        const uint8_t *base;
+        const uint64_t *offs, *sizes;
+        int rc = flo_batch_device_files(b, &base, &offs, &sizes);
+        if (rc != FLO_OK) return rc;
+        uint64_t n = 0;
+        for (size_t i = 0; i < b->n_clips; i++) n += (sizes[i] + 15) & ~(uint64_t)15;
+        *need = n;
+        return FLO_OK;
+    }
+    int pack(void *batch, Buffer &dst, uint64_t *bytes) {
+        flo_batch *b = (flo_batch *)batch;
+        pack_off.resize(b->n_clips + 1);
+        int rc = flo_batch_pack_files(b, dst.p, dst.cap, pack_off.data());
+        if (rc != FLO_OK) return rc;
+        *bytes = pack_off[b->n_clips];
+        return FLO_OK;
+    }
+    int wait_moved_before_pack(int s) {
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ev_moved[s], 0));
+        return FLO_OK;
+    }
+    int mark_packed(int s) {
+        HIPCHK(ctx, hipEventRecord(ev_packed[s], ctx->stream));
+        return FLO_OK;
+    }
+    int sizes_exchange(int s, uint64_t mine) {
+        flo_ctx *c = ctx;
+        *h_mine[s] = mine;
+        HIPCHK(c, hipMemcpyAsync(d_mine[s], h_mine[s], 8, hipMemcpyHostToDevice, cs));
+        NCCLRC(c, ncclAllGather(d_mine[s], d_sizes[s], 1, ncclUint64, comm, cs));
+        HIPCHK(c, hipMemcpyAsync(h_sizes[s], d_sizes[s], (size_t)world * 8, hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipEventRecord(ev_sizes[s], cs));
+        return FLO_OK;
+    }
+    int sizes_wait(int s, const uint64_t **sizes) {
+        HIPCHK(ctx, hipEventSynchronize(ev_sizes[s]));
+        *sizes = h_sizes[s];
+        return FLO_OK;
+    }
+    int comm_waits_for_pack(int s) {
+        HIPCHK(ctx, hipStreamWaitEvent(cs, ev_packed[s], 0));
+        return FLO_OK;
+    }
+    int copy_own(Buffer &dst, size_t off, Buffer &src, size_t n) {
+        HIPCHK(ctx, hipMemcpyAsync(dst.p + off, src.p, n, hipMemcpyDeviceToDevice, cs));
+        return FLO_OK;
+    }
+    int group_begin() {
+        NCCLRC(ctx, ncclGroupStart());
+        return FLO_OK;
+    }
+    int recv(Buffer &dst, size_t off, size_t n, int peer) {
+        NCCLRC(ctx, ncclRecv(dst.p + off, n, ncclUint8, peer, comm, cs));
+        return FLO_OK;
+    }
+    int send(Buffer &src, size_t n, int peer) {
+        NCCLRC(ctx, ncclSend(src.p, n, ncclUint8, peer, comm, cs));
+        return FLO_OK;
+    }
+    int group_end() {
+        NCCLRC(ctx, ncclGroupEnd());
+        return FLO_OK;
+    }
+    int mark_moved(int s) {
+        HIPCHK(ctx, hipEventRecord(ev_moved[s], cs));
+        return FLO_OK;
+    }
+    int drain() {
+        HIPCHK(ctx, hipStreamSynchronize(cs));
+        return FLO_OK;
+    }
 };
 
-#define NCCLCHK(ctx, expr)                                                                              \
-    do {                                                                                                \
-        ncclResult_t r_ = (expr);                                                                       \
-        if (r_ != ncclSuccess) return fail(ctx, FLO_ERR_DEVICE, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
-    } while (0)
+struct flo_dist {
+    flo_ctx *ctx = nullptr;
+    RcclBackend be;
+    flo::DistEngine<RcclBackend> eng;
+};
 
 extern "C" int flo_dist_unique_id(uint8_t *id) {
     if (!id) return FLO_ERR_ARG;
@@ -1649,21 +1746,22 @@ extern "C" int flo_dist_unique_id(uint8_t *id) {
 
 extern "C" void flo_dist_destroy(flo_dist *d) {
     if (!d) return;
+    RcclBackend &be = d->be;
     hipSetDevice(d->ctx->device);
-    if (d->cs) hipStreamSynchronize(d->cs);
+    if (be.cs) hipStreamSynchronize(be.cs);
     for (int s = 0; s < 2; s++) {
-        if (d->send[s]) hipFree(d->send[s]);
-        if (d->recv[s]) hipFree(d->recv[s]);
-        if (d->d_sizes[s]) hipFree(d->d_sizes[s]);
-        if (d->d_mine[s]) hipFree(d->d_mine[s]);
-        if (d->h_sizes[s]) hipHostFree(d->h_sizes[s]);
-        if (d->h_mine[s]) hipHostFree(d->h_mine[s]);
-        if (d->ev_packed[s]) hipEventDestroy(d->ev_packed[s]);
-        if (d->ev_sizes[s]) hipEventDestroy(d->ev_sizes[s]);
-        if (d->ev_moved[s]) hipEventDestroy(d->ev_moved[s]);
+        if (d->eng.send[s].p) hipFree(d->eng.send[s].p);
+        if (d->eng.recv[s].p) hipFree(d->eng.recv[s].p);
+        if (be.d_sizes[s]) hipFree(be.d_sizes[s]);
+        if (be.d_mine[s]) hipFree(be.d_mine[s]);
+        if (be.h_sizes[s]) hipHostFree(be.h_sizes[s]);
+        if (be.h_mine[s]) hipHostFree(be.h_mine[s]);
+        if (be.ev_packed[s]) hipEventDestroy(be.ev_packed[s]);
+        if (be.ev_sizes[s]) hipEventDestroy(be.ev_sizes[s]);
+        if (be.ev_moved[s]) hipEventDestroy(be.ev_moved[s]);
     }
-    if (d->comm) ncclCommDestroy(d->comm);
-    if (d->cs) hipStreamDestroy(d->cs);
+    if (be.comm) ncclCommDestroy(be.comm);
+    if (be.cs) hipStreamDestroy(be.cs);
     delete d;
 }
 
@@ -1673,76 +1771,32 @@ extern "C" int flo_dist_create(flo_ctx *c, const uint8_t *id, int rank, int worl
     HIPCHK(c, hipSetDevice(c->device));
     flo_dist *d = new flo_dist();
     d->ctx = c;
-    d->rank = rank;
-    d->world = world;
-    d->root = root;
+    RcclBackend &be = d->be;
+    be.ctx = c;
+    be.world = world;
+    d->eng.init(&be, rank, world, root);
     auto bail = [&](int rc) {
         flo_dist_destroy(d);
         return rc;
     };
-    if (hipStreamCreateWithFlags(&d->cs, hipStreamNonBlocking) != hipSuccess) return bail(fail(c, FLO_ERR_DEVICE, "hipStreamCreate (communication stream)"));
+    if (hipStreamCreateWithFlags(&be.cs, hipStreamNonBlocking) != hipSuccess) return bail(fail(c, FLO_ERR_DEVICE, "hipStreamCreate (communication stream)"));
     ncclUniqueId u;
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
-    ncclResult_t r = ncclCommInitRank(&d->comm, world, u, rank);
+    ncclResult_t r = ncclCommInitRank(&be.comm, world, u, rank);
     if (r != ncclSuccess) return bail(fail(c, FLO_ERR_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)));
     for (int s = 0; s < 2; s++) {
-        if (hipMalloc(&d->d_sizes[s], (size_t)world * 8) != hipSuccess || hipMalloc(&d->d_mine[s], 8) != hipSuccess ||
-            hipHostMalloc(&d->h_sizes[s], (size_t)world * 8) != hipSuccess || hipHostMalloc(&d->h_mine[s], 8) != hipSuccess ||
-            hipEventCreateWithFlags(&d->ev_packed[s], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&d->ev_sizes[s], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&d->ev_moved[s], hipEventDisableTiming) != hipSuccess)
+        if (hipMalloc(&be.d_sizes[s], (size_t)world * 8) != hipSuccess || hipMalloc(&be.d_mine[s], 8) != hipSuccess ||
+            hipHostMalloc(&be.h_sizes[s], (size_t)world * 8) != hipSuccess || hipHostMalloc(&be.h_mine[s], 8) != hipSuccess ||
+            hipEventCreateWithFlags(&be.ev_packed[s], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&be.ev_sizes[s], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&be.ev_moved[s], hipEventDisableTiming) != hipSuccess)
             return bail(fail(c, FLO_ERR_NOMEM, "flo_dist_create: buffers"));
     }
+    // RCCL's send / receive are kernels: with more than one rank the persistent chain kernel leaves a few compute units
+    // free for them, or the transfer of step k could not start before the encode of step k + 1 has ended
+    // (flo_ctx_reserve_cus; an explicit setting or FLO_RESERVE_CUS wins)
+    if (world > 1 && c->reserve_cus < 0) c->reserve_cus = kDefaultReservedCus;
     *out = d;
-    return FLO_OK;
-}
-
-// (re)allocate a device buffer to hold `need` bytes; growing waits for the work that may still use the old one
-static int dist_reserve(flo_dist *d, uint8_t **buf, size_t *cap, size_t need) {
-    if (*cap >= need) return FLO_OK;
-    flo_ctx *c = d->ctx;
-    HIPCHK(c, hipStreamSynchronize(d->cs));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (*buf) HIPCHK(c, hipFree(*buf));
-    *buf = nullptr;
-    *cap = 0;
-    const size_t want = need + need / 4 + 4096;
-    hipError_t e = hipMalloc(buf, want);
-    if (e != hipSuccess) return fail(c, FLO_ERR_NOMEM, std::string("gather buffer: ") + hipGetErrorString(e));
-    *cap = want;
-    return FLO_OK;
-}
-
-// post the point-to-point transfers of slot s (its sizes have arrived on the host, or are awaited here)
-static int dist_post(flo_dist *d, int s) {
-    flo_ctx *c = d->ctx;
-    if (d->posted[s]) return FLO_OK;
-    HIPCHK(c, hipEventSynchronize(d->ev_sizes[s]));   // recorded a whole step ago: no stall in steady state
-    const uint64_t *sz = d->h_sizes[s];
-    if (d->rank == d->root) {
-        uint64_t total = 0;
-        d->res_off.assign(d->world, 0);
-        d->res_size.assign(sz, sz + d->world);
-        for (int r = 0; r < d->world; r++) {
-            d->res_off[r] = total;
-            total += (sz[r] + 255) & ~(uint64_t)255;
-        }
-        int rc = dist_reserve(d, &d->recv[s], &d->recv_cap[s], total ? total : 256);
-        if (rc != FLO_OK) return rc;
-        // the root's own files: device-to-device copy on the communication stream
-        if (sz[d->root]) HIPCHK(c, hipMemcpyAsync(d->recv[s] + d->res_off[d->root], d->send[s], sz[d->root], hipMemcpyDeviceToDevice, d->cs));
-        NCCLCHK(c, ncclGroupStart());
-        for (int r = 0; r < d->world; r++)
-            if (r != d->root && sz[r]) NCCLCHK(c, ncclRecv(d->recv[s] + d->res_off[r], sz[r], ncclUint8, r, d->comm, d->cs));
-        NCCLCHK(c, ncclGroupEnd());
-        d->res_slot = s;
-    } else if (sz[d->rank]) {
-        NCCLCHK(c, ncclGroupStart());
-        NCCLCHK(c, ncclSend(d->send[s], sz[d->rank], ncclUint8, d->root, d->comm, d->cs));
-        NCCLCHK(c, ncclGroupEnd());
-    }
-    HIPCHK(c, hipEventRecord(d->ev_moved[s], d->cs));   // the slot's send buffer may be packed into again behind this
-    d->posted[s] = true;
     return FLO_OK;
 }
 
@@ -1752,64 +1806,33 @@ extern "C" int flo_dist_gather_submit(flo_dist *d, flo_batch *b) {
     if (b->ctx != c) return fail(c, FLO_ERR_ARG, "batch and communicator belong to different contexts");
     if (!b->synced) return fail(c, FLO_ERR_STATE, "call flo_batch_encode + flo_batch_sync first");
     HIPCHK(c, hipSetDevice(c->device));
-    const int s = (int)(d->submits & 1), prev = s ^ 1;
-    // 1. this slot's previous transfers (two submits ago) were posted one submit ago; its send buffer is free once they
-    //    have run: the pack kernel waits for that on the device, the host does not
-    int rc = dist_post(d, s);   // (only pending when submits were skipped; normally a no-op)
-    if (rc != FLO_OK) return rc;
-    // 2. pack this batch's finished files into the slot's send buffer (ctx stream)
-    const uint8_t *base;
-    const uint64_t *offs, *sizes;
-    rc = flo_batch_device_files(b, &base, &offs, &sizes);
-    if (rc != FLO_OK) return rc;
-    uint64_t need = 0;
-    for (size_t i = 0; i < b->n_clips; i++) need += (sizes[i] + 15) & ~(uint64_t)15;
-    rc = dist_reserve(d, &d->send[s], &d->send_cap[s], need ? need : 16);
-    if (rc != FLO_OK) return rc;
-    if (d->used[s]) HIPCHK(c, hipStreamWaitEvent(c->stream, d->ev_moved[s], 0));
-    d->pack_off.resize(b->n_clips + 1);
-    rc = flo_batch_pack_files(b, d->send[s], d->send_cap[s], d->pack_off.data());
-    if (rc != FLO_OK) return rc;
-    d->send_bytes[s] = d->pack_off[b->n_clips];
-    HIPCHK(c, hipEventRecord(d->ev_packed[s], c->stream));
-    // 3. sizes: all-gather on the communication stream, then to pinned host memory (asynchronous)
-    *d->h_mine[s] = d->send_bytes[s];
-    HIPCHK(c, hipMemcpyAsync(d->d_mine[s], d->h_mine[s], 8, hipMemcpyHostToDevice, d->cs));
-    NCCLCHK(c, ncclAllGather(d->d_mine[s], d->d_sizes[s], 1, ncclUint64, d->comm, d->cs));
-    HIPCHK(c, hipMemcpyAsync(d->h_sizes[s], d->d_sizes[s], (size_t)d->world * 8, hipMemcpyDeviceToHost, d->cs));
-    HIPCHK(c, hipEventRecord(d->ev_sizes[s], d->cs));
-    HIPCHK(c, hipStreamWaitEvent(d->cs, d->ev_packed[s], 0));   // the payload transfers (posted next submit) read the packed buffer
-    d->posted[s] = false;
-    d->used[s] = true;
-    d->submits++;
-    // 4. the transfers of the previous submit: their sizes arrived during the step that has just been encoded
-    return dist_post(d, prev);
+    return d->eng.submit(b);
 }
 
 extern "C" int flo_dist_gather_flush(flo_dist *d) {
     if (!d) return FLO_ERR_ARG;
-    flo_ctx *c = d->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
-    const int last = (int)((d->submits + 1) & 1);   // slot of the most recent submit
-    int rc = dist_post(d, last ^ 1);
-    if (rc == FLO_OK) rc = dist_post(d, last);
-    if (rc != FLO_OK) return rc;
-    HIPCHK(c, hipStreamSynchronize(d->cs));
-    return FLO_OK;
+    HIPCHK(d->ctx, hipSetDevice(d->ctx->device));
+    return d->eng.flush();
 }
 
 extern "C" int flo_dist_gather_result(flo_dist *d, const uint8_t **base, const uint64_t **rank_offsets,
                                       const uint64_t **rank_sizes) {
     if (!d) return FLO_ERR_ARG;
-    if (d->rank != d->root) return fail(d->ctx, FLO_ERR_STATE, "only the root holds the gathered files");
-    if (d->res_slot < 0) return fail(d->ctx, FLO_ERR_STATE, "nothing has been gathered yet");
-    if (base) *base = d->recv[d->res_slot];
-    if (rank_offsets) *rank_offsets = d->res_off.data();
-    if (rank_sizes) *rank_sizes = d->res_size.data();
+    if (d->eng.rank != d->eng.root) return fail(d->ctx, FLO_ERR_STATE, "only the root holds the gathered files");
+    if (d->eng.res_slot < 0) return fail(d->ctx, FLO_ERR_STATE, "nothing has been gathered yet");
+    if (base) *base = d->eng.recv[d->eng.res_slot].p;
+    if (rank_offsets) *rank_offsets = d->eng.res_off.data();
+    if (rank_sizes) *rank_sizes = d->eng.res_size.data();
     return FLO_OK;
 }
 
-extern "C" void *flo_dist_stream(flo_dist *d) { return d ? (void *)d->cs : nullptr; }
+extern "C" void *flo_dist_stream(flo_dist *d) { return d ? (void *)d->be.cs : nullptr; }
+
+extern "C" int flo_ctx_reserve_cus(flo_ctx *c, int n) {
+    if (!c || n < 0 || n >= c->prop.multiProcessorCount) return FLO_ERR_ARG;
+    c->reserve_cus = n;
+    return FLO_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ streaming encoder
 // StreamingEncoder of libflo/src/streaming/encoder.rs on the device library: samples are pushed, complete one-second

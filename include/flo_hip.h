@@ -169,6 +169,11 @@ int flo_dist_gather_flush(flo_dist *d);
  * in their headers) lie at base + rank_offsets[r], rank_sizes[r] bytes, in device memory owned by d */
 int flo_dist_gather_result(flo_dist *d, const uint8_t **base, const uint64_t **rank_offsets, const uint64_t **rank_sizes);
 void *flo_dist_stream(flo_dist *d);   /* hipStream_t of the communication stream */
+/* The persistent encode kernels start one workgroup per compute unit; RCCL's send / receive are kernels too, so with
+ * more than one rank the library leaves `n` compute units free for them (default 8 once a communicator with world > 1
+ * exists, 0 otherwise; the environment variable FLO_RESERVE_CUS sets it at context creation). Costs n / 256 of the
+ * single-GPU rate; without it the transfer of step k cannot start before the encode of step k + 1 has ended. */
+int flo_ctx_reserve_cus(flo_ctx *ctx, int n);
 
 /* ---- analysis metadata: what libflo::encode / encode_lossy / encode_with_bitrate add to META (lib.rs:219-283) -------
  * flo_analyze computes, on the device, what add_analysis_data_if_missing computes from the samples: waveform peaks

@@ -1,4 +1,6 @@
-"""N > 1 host logic on CPU: clip sharding and the variable-size gather, world_size 2 over gloo."""
+"""N > 1 host logic on CPU: clip sharding; the exchange step's C++ ordering logic (flo_amd/csrc/dist_engine.hpp, the template
+flo_dist_* instantiates with RCCL) run with 2, 3 and 5 ranks over sockets; and the protocol's Python reference
+(tests/dist_ref.py), world_size 2 over gloo."""
 import os
 import socket
 
@@ -8,7 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from flo_amd.dist import PipelinedGather, contiguous_shard, gather_payloads, shard_clips
+from dist_ref import PipelinedGather, gather_payloads
+from flo_amd.dist import contiguous_shard, shard_clips
 
 
 def test_shard_clips_partition_and_balance():
@@ -134,3 +137,17 @@ def test_pipelined_gather_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_dist_engine_state_machine_with_several_ranks(tmp_path):
+    # the product's own slot / ordering logic (DistEngine: deferred posting, slot parity, growing buffers, empty payloads,
+    # a flush in the middle), bound to sockets instead of RCCL: one process per rank
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "dist_engine_test")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=address,undefined", "-o", exe,
+                    os.path.join(ROOT, "tests", "native", "dist_engine_test.cpp")], check=True)
+    for world, steps in ((1, 7), (2, 7), (3, 8), (5, 6), (2, 1), (3, 2)):
+        r = subprocess.run([exe, str(world), str(steps)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (world, steps, r.stdout, r.stderr)
+        assert "runtime error" not in r.stderr, r.stderr

@@ -1,7 +1,8 @@
 """The multi-GPU exchange step behind the C ABI (flo_dist_*: RCCL directly). A gpurun box has one GPU: the single-rank
 case runs the whole code path (all-gather of sizes, root copy, double buffering, deferred posting); the two-rank case
-puts two processes on the same GPU, which RCCL may refuse - then it is skipped and N > 1 stays covered by the gloo
-logic tests of test_dist_cpu.py plus the driver's multi-GPU run."""
+puts two processes on the same GPU, which RCCL refuses with "invalid usage" on this pool - ONLY that refusal skips the
+test, every other error or a timeout fails it. The ordering logic itself runs with several ranks on the CPU
+(tests/native/dist_engine_test.cpp through test_dist_cpu.py); N > 1 on hardware is the driver's multi-GPU run."""
 import ctypes
 import multiprocessing as mp
 import os
@@ -111,12 +112,17 @@ def test_two_ranks_on_one_gpu_if_rccl_allows_it():
     except Exception:   # noqa: BLE001
         for p in procs:
             p.kill()
-        pytest.skip("two RCCL ranks on one GPU did not come up on this box (N > 1 is the driver's multi-GPU run)")
+        # a rank that died or hung is a failure: the one condition that excuses this test is RCCL's documented refusal
+        pytest.fail(f"a rank did not report within 240 s (got {[r[:2] for r in res]})")
     for p in procs:
         p.join(timeout=60)
     errs = [r for r in res if r[0] == "error"]
     if errs:
-        pytest.skip(f"RCCL refused two ranks on one GPU: {errs[0][2][:200]}")
+        msgs = " | ".join(e[2][:300] for e in errs)
+        refused = ("invalid usage" in msgs.lower() or "duplicate gpu" in msgs.lower()) and "ncclCommInitRank" in msgs
+        if refused and all("ncclCommInitRank" in e[2] for e in errs):
+            pytest.skip(f"RCCL refuses two ranks on one GPU (ncclCommInitRank: invalid usage): {msgs[:200]}")
+        pytest.fail(f"the two-rank exchange failed: {msgs}")
     root = [r for r in res if r[0] == "root"][0]
     peer = [r for r in res if r[0] == "peer"][0]
     got = root[1]

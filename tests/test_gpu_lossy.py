@@ -386,7 +386,7 @@ def test_pack_streams_and_single_rank_rccl_gather(ctx):
     import torch
     import torch.distributed as dist
     import flo_amd
-    from flo_amd.dist import gather_payloads
+    from dist_ref import gather_payloads
     clips = [signals.music_like(44100, n, 2, seed=n) for n in (5000, 44100, 12345)]
     b = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [c.size for c in clips], 44100, 2, 0.55)
     for i, c in enumerate(clips):
@@ -416,7 +416,7 @@ def test_pack_streams_and_single_rank_rccl_gather(ctx):
         got, sizes = gather_payloads(dist, buf[: offs[-1]], 0, 1, 0)
         assert sizes == [offs[-1]] and got[0].data_ptr() == buf.data_ptr()
         # the per-step object bench.py uses for N > 1: packs finished files, double-buffered, pipelined
-        from flo_amd.dist import BitstreamGather
+        from dist_ref import BitstreamGather
         g = BitstreamGather(ctx, b, dist, 0, 1, 0)
         for _ in range(3):
             b.encode(0)
