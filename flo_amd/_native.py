@@ -36,7 +36,8 @@ class Analysis(C.Structure):
     _fields_ = [("n_peaks", C.c_uint32), ("duration_ms", C.c_uint32), ("sample_rate", C.c_uint32), ("channels", C.c_uint8),
                 ("avg_loudness", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_uint8), ("hash", C.c_uint8 * 32),
                 ("frequency_peaks", C.c_uint8 * 8), ("energy_profile", C.c_uint8 * 16), ("integrated_lufs", C.c_double),
-                ("length_ms", C.c_uint64)]
+                ("length_ms", C.c_uint64), ("loudness_range_lu", C.c_double), ("true_peak_dbtp", C.c_double),
+                ("sample_peak_dbfs", C.c_double)]
 
 
 class ContainerInfo(C.Structure):

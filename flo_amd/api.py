@@ -172,7 +172,8 @@ class Context:
                                       peaks.ctypes.data, peaks.size, C.byref(a)))
         return dict(peaks=peaks[: a.n_peaks].copy(), hash=bytes(a.hash), duration_ms=a.duration_ms, sample_rate=a.sample_rate,
                     channels=a.channels, frequency_peaks=list(a.frequency_peaks), energy_profile=list(a.energy_profile),
-                    avg_loudness=a.avg_loudness, integrated_lufs=a.integrated_lufs, length_ms=a.length_ms)
+                    avg_loudness=a.avg_loudness, integrated_lufs=a.integrated_lufs, length_ms=a.length_ms,
+                    loudness_range_lu=a.loudness_range_lu, true_peak_dbtp=a.true_peak_dbtp, sample_peak_dbfs=a.sample_peak_dbfs)
 
     def analysis_metadata(self, samples, sample_rate, channels, peaks_per_second=50) -> bytes:
         """add_analysis_data_if_missing(&[], ...): the MessagePack META libflo::encode* build for an empty input META"""

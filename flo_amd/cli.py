@@ -8,12 +8,14 @@ printed fields for the parts that sit on this repository's path -
     info    <in.flo>
     validate <in.flo>
     metadata <in.flo> [--json]
+    analysis <in.flo> [--waveform] [--spectrum] [--json]
 Ingestion is WAV only (flo_amd/wav.py; the reference demuxes MP3/FLAC/OGG/AAC through symphonia, reflo/src/audio.rs:57-166).
 `encode` writes the META chunk the reference CLI writes for an untagged file (reflo/src/lib.rs:202-283, flo_amd/meta.py):
 length_ms, encoding_time, encoder_settings, flo_encoder_version, source_format (+ --title / --artist / --album) - the
 reference-made Examples/*.flo are reproduced including META, the encoding time aside. Tags inside the source file
-(RIFF INFO) are not carried over, and the `analysis` sub-command (waveform, fingerprint, EBU R128 of
-libflo/src/core/analysis.rs, ebu_r128.rs) is not offered: that analysis is outside this repository's path.
+(RIFF INFO) are not carried over. `analysis` (reflo/src/main.rs:619-800) decodes the file and prints what flo_analyze
+computes on the device: EBU R128 loudness, range, true peak and sample peak (core/ebu_r128.rs), and on request the
+waveform peaks at 60 per second and the spectral fingerprint (core/analysis.rs).
 The quality names map as in the reference CLI (main.rs:236-242): low 0.2, medium 0.4, high 0.6, veryhigh 0.8,
 transparent 1.0 - NOT the QualityPreset values the library API uses (lossy/mod.rs:39-47).
 """
@@ -92,6 +94,36 @@ def flo_info(flo_bytes: bytes) -> dict:
                 lossy_quality=(i.flags >> 8) & 0x0F, compression_level=i.compression_level)
 
 
+def analysis_report(flo_bytes: bytes, waveform=False, spectrum=False, ctx=None) -> dict:
+    """What reflo's `analysis` command gathers (reflo/src/main.rs:619-735): file info, compute_ebu_r128_loudness on the
+    decoded samples, optionally extract_waveform_peaks at 60 peaks per second and extract_spectral_fingerprint."""
+    import numpy as np
+    c = ctx or api.default_context()
+    info = flo_info(flo_bytes)
+    pcm, sr, ch = c.decode(flo_bytes, with_info=True)
+    a = c.analyze(pcm, info["sample_rate"], info["channels"], 60)
+    out = {"file_info": {"sample_rate": info["sample_rate"], "channels": info["channels"], "bit_depth": info["bit_depth"],
+                         "duration_secs": info["duration_secs"], "total_samples": info["total_samples"]},
+           "loudness": {"integrated_lufs": a["integrated_lufs"], "loudness_range_lu": a["loudness_range_lu"],
+                        "true_peak_dbtp": a["true_peak_dbtp"], "sample_peak_dbfs": a["sample_peak_dbfs"]},
+           "waveform": None, "spectral": None}
+    if waveform:
+        pk = a["peaks"]
+        stats = None
+        if pk.size:
+            # (the reference averages with a sequential f32 sum: main.rs:662)
+            acc = np.float32(0.0)
+            for v in pk:
+                acc = np.float32(acc + v)
+            stats = {"min": float(pk.min()), "max": float(pk.max()), "average": float(acc / np.float32(pk.size))}
+        out["waveform"] = {"peaks_per_second": 60, "total_peaks": int(pk.size), "channels": info["channels"], "peak_statistics": stats}
+    if spectrum:
+        out["spectral"] = {"duration_ms": a["duration_ms"], "sample_rate": a["sample_rate"], "channels": a["channels"],
+                           "peak_frequency_bands": list(a["frequency_peaks"]), "energy_profile": list(a["energy_profile"]),
+                           "average_loudness": a["avg_loudness"], "spectral_hash_hex": a["hash"][:8].hex()}
+    return out
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="flo", description="flo audio format converter (MI355X-native encode / decode)")
     sub = ap.add_subparsers(dest="command", required=True)
@@ -116,6 +148,11 @@ def main(argv=None) -> int:
     m.add_argument("--json", action="store_true", help="Output as JSON")
     v = sub.add_parser("validate", help="Validate a flo file")
     v.add_argument("input")
+    an = sub.add_parser("analysis", help="Analyze audio with waveform peaks and spectral fingerprinting")
+    an.add_argument("input")
+    an.add_argument("-w", "--waveform", action="store_true", help="Show waveform peaks")
+    an.add_argument("-s", "--spectrum", action="store_true", help="Show spectral fingerprint")
+    an.add_argument("--json", action="store_true", help="Output as JSON")
     a = ap.parse_args(argv)
     try:
         if a.command == "encode":
@@ -186,6 +223,55 @@ def main(argv=None) -> int:
                 for k, v in md.items():
                     shown = f"<{len(v)} bytes>" if isinstance(v, (bytes, list)) and len(v) > 16 else v
                     print(f"  {k}: {shown}")
+        elif a.command == "analysis":
+            rep = analysis_report(open(a.input, "rb").read(), a.waveform, a.spectrum)
+            if a.json:
+                print(json.dumps(rep, indent=2))
+            else:
+                fi, lo = rep["file_info"], rep["loudness"]
+                print(f"Analyzing {a.input}...")
+                print()
+                print("File Information")
+                print("\u2500" * 16)
+                print(f"  Sample rate: {fi['sample_rate']} Hz")
+                print(f"  Channels:    {fi['channels']}")
+                print(f"  Bit depth:   {fi['bit_depth']} bits")
+                print(f"  Duration:    {fi['duration_secs']:.2f}s")
+                print(f"  Total samples: {fi['total_samples']}")
+                print()
+                print("Loudness Metrics (EBU R128)")
+                print("\u2500" * 28)
+                print(f"  Integrated loudness: {lo['integrated_lufs']:.2f} LUFS")
+                print(f"  Loudness range:      {lo['loudness_range_lu']:.2f} LU")
+                print(f"  True peak:           {lo['true_peak_dbtp']:.2f} dBTP")
+                print(f"  Sample peak:         {lo['sample_peak_dbfs']:.2f} dBFS")
+                print()
+                if rep["waveform"]:
+                    wf = rep["waveform"]
+                    print("Waveform Analysis")
+                    print("\u2500" * 17)
+                    print(f"  Peaks per second:    {wf['peaks_per_second']}")
+                    print(f"  Total peaks:         {wf['total_peaks']}")
+                    print(f"  Channels:            {wf['channels']}")
+                    if wf["peak_statistics"]:
+                        st = wf["peak_statistics"]
+                        print("  Peak statistics:")
+                        print(f"    Min:               {st['min']:.6f}")
+                        print(f"    Max:               {st['max']:.6f}")
+                        print(f"    Average:           {st['average']:.6f}")
+                    print()
+                if rep["spectral"]:
+                    sp = rep["spectral"]
+                    print("Spectral Analysis")
+                    print("\u2500" * 17)
+                    print(f"  Duration:            {sp['duration_ms']} ms")
+                    print(f"  Sample rate:         {sp['sample_rate']} Hz")
+                    print(f"  Channels:            {sp['channels']}")
+                    print(f"  Peak frequency bands: {sp['peak_frequency_bands']}")
+                    print(f"  Energy profile (16 bands): {sp['energy_profile']}")
+                    print(f"  Average loudness:    {sp['average_loudness']}")
+                    print(f"  Spectral hash (first 8 bytes):   {sp['spectral_hash_hex']}")
+                    print()
         elif a.command == "validate":
             try:
                 ok = flo_info(open(a.input, "rb").read())["crc_valid"]

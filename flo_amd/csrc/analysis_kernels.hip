@@ -4,12 +4,13 @@
 //   extract_waveform_peaks ............. core/analysis.rs:38-115      an_peaks_kernel (one wave per peak window)
 //   extract_spectral_fingerprint ....... core/analysis.rs:223-357     an_blake3_chunks / an_blake3_tree (the hash; BLAKE3
 //                                        is a tree of 1 KiB chunks, so chunks hash in parallel), an_fft_kernel (the three
-//                                        256-point sections), the sequential f32 sum of squares in an_scan_kernel
-//   compute_ebu_r128_loudness .......... core/ebu_r128.rs:182-266      an_scan_kernel: K-weighting (two biquads, f64) and the
-//                                        400 ms block sums, one lane per channel walking the samples in order
+//                                        256-point sections), the f32 sum of squares in an_sumsq_kernel
+//   compute_ebu_r128_loudness .......... core/ebu_r128.rs:112-266      an_loud_kernel: K-weighting (two biquads, f64), the
+//                                        400 ms block sums, the sample peak and the true-peak FIR
 // Everything the reference accumulates sequentially is accumulated in the same order here (the sums feed truncating
-// casts to u8 and an f32 cast of the loudness, so the order matters for byte equality); only order-free work (maxima,
-// the hash tree, butterflies) is spread over lanes. Compiled with -ffp-contract=off like the other kernels.
+// casts to u8 and an f32 cast of the loudness, so the order matters for byte equality) - exactly so for clips up to one
+// segment (65 536 frames; 65 536 interleaved samples for the sum of squares), in segments with a filter warm-up beyond (see "order-bound scans" below); only order-free work
+// (maxima, the hash tree, butterflies, the FIR outputs) is spread over lanes. Compiled with -ffp-contract=off.
 #include "analysis_kernels.hpp"
 
 namespace flo {
@@ -69,62 +70,158 @@ __global__ __launch_bounds__(64) void an_peaks_kernel(AnalysisArgs A) {
     if (lane == 0) A.peaks[idx] = peak;
 }
 
-// ------------------------------------------------------------------------------------------------ sequential scans
-// thread 0: sum of s*s over all samples, f32, in order (analysis.rs:338). thread 1 + c: channel c through the
-// K-weighting filter, its squares summed into the (up to four) 400 ms blocks that contain the sample, each block's
-// sum in sample order (ebu_r128.rs:219-262).
-__global__ __launch_bounds__(64) void an_scan_kernel(AnalysisArgs A) {
-    // one WAVE per scan (lane 0 works): scans in one wave would run one after the other
-    if (threadIdx.x != 0) return;
-    const unsigned t = blockIdx.x;
-    const unsigned ch = A.channels;
-    if (t == 0) {
-        float acc = 0.f;
-        for (unsigned long long i = 0; i < A.n; i++) {
-            const float s = A.pcm[i];
-            acc += s * s;
-        }
-        A.sumsq[0] = acc;
-        return;
-    }
-    const unsigned c = t - 1;
-    if (c >= ch) return;
-    const unsigned long long frames = A.n / ch;
+// ------------------------------------------------------------------------------------------------ order-bound scans
+// What the reference accumulates sample after sample - the f32 sum of squares (analysis.rs:338), the K-weighting
+// recurrence and the 400 ms block sums (ebu_r128.rs:219-262) - is a dependent chain: one lane walks it. Round 2 walked a
+// whole clip with ONE lane reading global memory sample by sample (180 ms for a 10 s clip, 3.2 s for three minutes: the
+// load latency, not the arithmetic). Now:
+//   * the samples come through LDS in tiles the whole workgroup loads (coalesced), the walking lane reads LDS;
+//   * a clip is cut into SEGMENTS that run in parallel. The first segment starts from the reference's zero state, so a
+//     clip shorter than one segment is bit for bit the reference's sequential result. Every further segment runs the two
+//     biquads `warm_frames` ahead of its first frame from a zero state: the filters' slowest mode (the 38 Hz high-pass,
+//     pole radius exp(-2 pi 38 / fs)) has decayed by exp(-59) over the quarter second of warm-up, twenty orders of
+//     magnitude below a double's resolution, so the states agree with the sequential ones to the last bit or the one
+//     before it; a block that straddles two segments is the sum of two partial sums. Loudness enters the META chunk as
+//     an f32: long clips equal the sequential result to ~1e-15 relative in the block energies.
+//   * the partial f32 sums of squares of the segments are added in order on the host.
+// A second wave of the same workgroup evaluates, on the same tiles, what is order-free: the sample peak and the 49-tap
+// FIR of compute_true_peak (each output is its own short sequential sum, taps in the reference's order).
+constexpr int kAnTile = 2048;   // frames per tile
+constexpr int kAnHalo = 24;     // (taps - 1) / 2
+
+__device__ __forceinline__ void atomic_max_f64_bits(unsigned long long *p, double v) {
+    if (v > 0.0) atomicMax(p, (unsigned long long)__double_as_longlong(v));
+}
+
+__global__ __launch_bounds__(128) void an_loud_kernel(AnalysisArgs A) {
+    __shared__ double xt[kAnTile + 2 * kAnHalo];
+    const unsigned seg = blockIdx.x, c = blockIdx.y, ch = A.channels;
+    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned long long frames = A.n / ch;                                   // whole sample-frames (K-weighting, sample peak)
+    const unsigned long long n_ch = A.n > c ? (A.n - c + ch - 1) / ch : 0;        // samples of channel c (the FIR walks these)
+    const unsigned long long own0 = (unsigned long long)seg * A.seg_frames;
+    unsigned long long own1 = own0 + A.seg_frames;
+    const bool last = seg + 1 == A.n_seg;
+    if (last) own1 = n_ch;                                                        // (n_ch >= frames: the last segment owns the tail)
+    if (own0 >= n_ch) return;
+    const unsigned long long run0 = own0 > A.warm_frames ? own0 - A.warm_frames : 0;
     const unsigned hop = A.hop;
-    double s1 = 0, s2 = 0, h1 = 0, h2 = 0;
-    double acc[4] = {0, 0, 0, 0};
-    double *out = A.block_sums + (unsigned long long)c * A.n_blocks;
-    // block k covers frames [k hop, min(k hop + 4 hop, frames)); the last block is the first one that reaches `frames`
-    unsigned long long next_edge = hop;   // frame index at which a block starts (and, four hops later, one ends)
-    unsigned k_start = 0;                 // blocks started so far - 1 = index of the newest block
-    for (unsigned long long i = 0; i < frames; i++) {
-        if (hop && i == next_edge) {
-            // a new block starts here; the block that started four hops ago ended with the previous sample
-            k_start++;
-            if (k_start >= 4) {
-                const unsigned done = k_start - 4;
-                if (done < A.n_blocks) out[done] = acc[done & 3];
-            }
-            acc[k_start & 3] = 0.0;
-            next_edge += hop;
+    // walking lane's state. a0..a3 are the sums of the (up to four) blocks alive: a_j belongs to block k_start - j. They are
+    // named registers that rotate when a block starts - an array indexed by k_start & 3 lives in scratch memory, and every
+    // one of its four updates per sample then costs a memory round trip (that, not the arithmetic, was this kernel's time).
+    double s1 = 0, s2 = 0, h1 = 0, h2 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    unsigned long long k_start = hop ? own0 / hop : 0, next_edge = hop ? (k_start + 1) * (unsigned long long)hop : ~0ull;
+    double *part = A.block_part + (unsigned long long)c * A.n_blocks * 2;
+    auto put_block = [&](long long k, double v) {   // block k's sum as far as this segment saw it
+        if (k >= 0 && (unsigned long long)k < A.n_blocks) part[2 * k + (((unsigned long long)k * hop >= own0) ? 0 : 1)] = v;
+    };
+    double peak_x = 0.0, peak_fir = 0.0;
+    for (unsigned long long t0 = run0; t0 < own1; t0 += kAnTile) {
+        __syncthreads();
+        for (unsigned i = tid; i < kAnTile + 2 * kAnHalo; i += 128) {
+            const long long f = (long long)t0 - kAnHalo + (long long)i;
+            xt[i] = (f >= 0 && (unsigned long long)f < n_ch) ? (double)A.pcm[(unsigned long long)f * ch + c] : 0.0;
         }
-        const double x = (double)A.pcm[i * ch + c];
-        const double y = A.shelf[0] * x + s1;
-        s1 = A.shelf[1] * x - A.shelf[3] * y + s2;
-        s2 = A.shelf[2] * x - A.shelf[4] * y;
-        const double y2 = A.hp[0] * y + h1;
-        h1 = A.hp[1] * y - A.hp[3] * y2 + h2;
-        h2 = A.hp[2] * y - A.hp[4] * y2;
-        const double e = y2 * y2;
-        // the blocks alive at this sample: k_start, k_start - 1, .. down to max(0, k_start - 3)
-        acc[k_start & 3] += e;
-        if (k_start >= 1) acc[(k_start - 1) & 3] += e;
-        if (k_start >= 2) acc[(k_start - 2) & 3] += e;
-        if (k_start >= 3) acc[(k_start - 3) & 3] += e;
+        __syncthreads();
+        const unsigned long long t1 = t0 + kAnTile < own1 ? t0 + kAnTile : own1;
+        if (wave == 0) {
+            if (lane == 0) {
+                const unsigned long long e1 = t1 < frames ? t1 : frames;
+                for (unsigned long long i8 = t0; i8 < e1; i8 += 8) {
+                    double xv[8];   // eight LDS reads in flight ahead of the dependent chain
+#pragma unroll
+                    for (int j = 0; j < 8; j++) xv[j] = xt[(unsigned)(i8 - t0) + kAnHalo + j];   // (the tile has 24 spare entries behind it)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const unsigned long long i = i8 + j;
+                        if (i >= e1) break;
+                        const double x = xv[j];
+                        const double y = A.shelf[0] * x + s1;
+                        s1 = A.shelf[1] * x - A.shelf[3] * y + s2;
+                        s2 = A.shelf[2] * x - A.shelf[4] * y;
+                        const double y2 = A.hp[0] * y + h1;
+                        h1 = A.hp[1] * y - A.hp[3] * y2 + h2;
+                        h2 = A.hp[2] * y - A.hp[4] * y2;
+                        if (i < own0) continue;   // warm-up: the filters run, nothing is summed
+                        if (i == next_edge) {
+                            // a new block starts here; the block that started four hops ago ended with the previous sample
+                            k_start++;
+                            put_block((long long)k_start - 4, a3);
+                            a3 = a2;
+                            a2 = a1;
+                            a1 = a0;
+                            a0 = 0.0;
+                            next_edge += hop;
+                        }
+                        const double e = y2 * y2;
+                        // every block alive at this sample (accumulators of blocks before the clip's first are never read)
+                        a0 += e;
+                        a1 += e;
+                        a2 += e;
+                        a3 += e;
+                    }
+                }
+            }
+        } else {
+            const unsigned long long b0 = t0 > own0 ? t0 : own0;
+            for (unsigned long long i = b0 + lane; i < t1; i += 64) {
+                const unsigned o = (unsigned)(i - t0);
+                if (i < frames) {
+                    const double a = fabs(xt[o + kAnHalo]);
+                    if (a > peak_x) peak_x = a;   // (a NaN sample never wins, as with f64::max)
+                }
+                double a2 = 0.0;
+#pragma unroll 7
+                for (int k = 0; k < 49; k++) {
+                    // taps whose sample lies outside the channel are skipped by the reference: the tile holds zeros there,
+                    // and adding x * 0 = +-0 leaves the sum unchanged (a NaN or infinite sample cannot sit outside)
+                    a2 += xt[o + k] * A.tp_coef[k];
+                }
+                a2 = fabs(a2);
+                if (a2 > peak_fir) peak_fir = a2;
+            }
+        }
     }
-    // blocks still open at the end: the reference stops at the first block whose end is `frames` (n_blocks counts them)
-    for (unsigned k = (k_start >= 3 ? k_start - 3 : 0); k <= k_start; k++)
-        if (k < A.n_blocks) out[k] = acc[k & 3];
+    if (wave == 0) {
+        if (lane == 0 && hop && own0 < frames) {
+            // blocks still open when the segment ends: partial sums (a later segment adds its share) or, in the last
+            // segment, the blocks that reach the end of the clip (n_blocks counts the ones the reference makes)
+            put_block((long long)k_start - 3, a3);
+            put_block((long long)k_start - 2, a2);
+            put_block((long long)k_start - 1, a1);
+            put_block((long long)k_start, a0);
+        }
+    } else {
+        for (int o = 32; o; o >>= 1) {
+            const double px = __shfl_xor(peak_x, o), pf = __shfl_xor(peak_fir, o);
+            peak_x = px > peak_x ? px : peak_x;
+            peak_fir = pf > peak_fir ? pf : peak_fir;
+        }
+        if (lane == 0) {
+            atomic_max_f64_bits(A.peak_bits, peak_x);
+            atomic_max_f64_bits(A.peak_bits + 1, peak_fir);
+        }
+    }
+}
+
+// f32 sum of s * s over the interleaved samples in order (analysis.rs:338), one wave per segment of A.sq_seg samples
+__global__ __launch_bounds__(64) void an_sumsq_kernel(AnalysisArgs A) {
+    __shared__ float xs[4096];
+    const unsigned long long b0 = (unsigned long long)blockIdx.x * A.sq_seg;
+    const unsigned long long b1 = b0 + A.sq_seg < A.n ? b0 + A.sq_seg : A.n;
+    float acc = 0.f;
+    for (unsigned long long t0 = b0; t0 < b1; t0 += 4096) {
+        const unsigned cnt = b1 - t0 < 4096 ? (unsigned)(b1 - t0) : 4096u;
+        for (unsigned i = threadIdx.x; i < cnt; i += 64) xs[i] = A.pcm[t0 + i];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (unsigned i = 0; i < cnt; i++) {
+                const float s = xs[i];
+                acc += s * s;
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) A.sumsq_part[blockIdx.x] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ BLAKE3
@@ -307,7 +404,9 @@ int launch_analysis(const AnalysisArgs &A, hipStream_t s) {
         AN_LAUNCH_CHECK();
     }
     if (A.n) {
-        hipLaunchKernelGGL(an_scan_kernel, dim3(A.channels + 1), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(an_loud_kernel, dim3(A.n_seg, A.channels), dim3(128), 0, s, A);
+        AN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(an_sumsq_kernel, dim3(A.n_sq_seg), dim3(64), 0, s, A);
         AN_LAUNCH_CHECK();
         hipLaunchKernelGGL(an_blake3_chunks_kernel, dim3((unsigned)((A.n_chunks + 127) / 128)), dim3(128), 0, s, A);
         AN_LAUNCH_CHECK();

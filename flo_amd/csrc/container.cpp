@@ -167,16 +167,19 @@ int parse_file(const uint8_t *data, size_t len, ParsedFile &f, const char **err)
 }
 
 uint32_t host_crc32(const uint8_t *data, size_t len) {
-    static uint32_t table[256];
-    static bool have = false;
-    if (!have) {
+    struct Table {
+        uint32_t v[256];
+    };
+    static const Table tbl = [] {   // thread-safe one-time initialisation
+        Table t{};
         for (uint32_t i = 0; i < 256; i++) {
             uint32_t c = i;
             for (int k = 0; k < 8; k++) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
-            table[i] = c;
+            t.v[i] = c;
         }
-        have = true;
-    }
+        return t;
+    }();
+    const uint32_t (&table)[256] = tbl.v;
     uint32_t crc = 0xFFFFFFFFu;
     for (size_t i = 0; i < len; i++) crc = table[(crc ^ data[i]) & 0xFFu] ^ (crc >> 8);
     return crc ^ 0xFFFFFFFFu;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -1169,6 +1170,17 @@ struct DevMem {   // frees on scope exit
     template <class T>
     T *as() const { return reinterpret_cast<T *>(p); }
 };
+// Declared right behind a function's DevMem objects, so that it is destroyed BEFORE them: whatever way the function is
+// left (an error return in the middle included), the context's stream is idle when the blocks go back to the pool, where
+// another context or thread may be handed them at once. On the normal path the stream has been synchronised already and
+// this costs a few microseconds.
+struct QuiesceOnExit {
+    flo_ctx *c;
+    explicit QuiesceOnExit(flo_ctx *ctx) : c(ctx) {}
+    ~QuiesceOnExit() {
+        if (c && c->stream) hipStreamSynchronize(c->stream);
+    }
+};
 template <class T>
 int upload(flo_ctx *c, DevMem &m, const std::vector<T> &v) {
     size_t bytes = v.size() * sizeof(T);
@@ -1293,6 +1305,7 @@ static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes,
     const size_t n_out = (size_t)w.out_sf * (size_t)nch;
     if (!n_out) return FLO_OK;
     DevMem d_ch, d_fr, d_scr, d_t0, d_ser, d_tabs, d_ent;
+    QuiesceOnExit quiesce_d_ch(c);
     int rc;
     if ((rc = upload(c, d_ch, w.chs)) || (rc = upload(c, d_fr, w.frs))) return rc;
     // Rice tiles per wrapper; wrappers the parallel form does not take (rice.rs k > 14; coefficient sums or shifts
@@ -1356,6 +1369,7 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
     if (channels) *channels = f.channels;
     const int nch = f.channels;
     DevMem d_bytes;
+    QuiesceOnExit quiesce_d_bytes(c);
     HIPCHK(c, pool_alloc(&d_bytes.p, len + 32));
     {
         int rc = ctx_stager(c);
@@ -1391,6 +1405,7 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
                 return rc;
             }
             DevMem d_off, d_len, d_c0, d_cn, d_co, d_out, d_err;
+            QuiesceOnExit quiesce_d_off(c);
             std::vector<unsigned long long> c0{0}, co{0};
             std::vector<unsigned int> cn{(unsigned int)nf};
             std::vector<int> zero{0};
@@ -1451,6 +1466,7 @@ static int decode_impl(flo_ctx *c, const uint8_t *flo, size_t len, float **pcm, 
     if ((pcm && !host) || (pcm_i32 && !host_i)) return bail(fail(c, FLO_ERR_NOMEM, "out of host memory"));
     if (n_out) {
         DevMem d_out, d_outi;
+        QuiesceOnExit quiesce_d_out(c);
         int rc;
         hipError_t e = hipSuccess;
         if (host) e = pool_alloc(&d_out.p, n_out * sizeof(float));
@@ -1564,6 +1580,7 @@ extern "C" int flo_batch_decode(flo_batch *b, float *dst, size_t dst_cap, uint64
     if (total > dst_cap) return fail(c, FLO_ERR_ARG, "destination too small for the decoded batch");
     if (!total) return FLO_OK;
     DevMem d_off, d_len, d_c0, d_cn, d_co, d_err;
+    QuiesceOnExit quiesce_d_off(c);
     std::vector<int> zero{0};
     int rc;
     if ((rc = upload(c, d_off, blob_off)) || (rc = upload(c, d_len, blob_len)) || (rc = upload(c, d_c0, c0)) ||
@@ -2112,6 +2129,9 @@ extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, 
     out->sample_rate = sr;
     out->channels = ch;
     out->integrated_lufs = -23.0;
+    out->loudness_range_lu = 0.0;
+    out->true_peak_dbtp = -150.0;
+    out->sample_peak_dbfs = -150.0;
     out->length_ms = (uint64_t)((double)(n / ch) / (double)sr * 1000.0);
     HIPCHK(c, hipSetDevice(c->device));
     AnalysisArgs A{};
@@ -2164,6 +2184,29 @@ extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, 
         }
     }
     A.n_blocks = (unsigned)block_len.size();
+    // segments of the order-bound scans (analysis_kernels.hip): a block must not span more than two of them, and the
+    // warm-up is a quarter of a second (the 38 Hz high-pass has decayed by exp(-59) then)
+    A.seg_frames = 65536u > 8u * A.hop ? 65536u : 8u * A.hop;
+    A.warm_frames = 8192u > sr / 4u ? 8192u : sr / 4u;
+    {
+        const uint64_t longest = (n + ch - 1) / ch;   // samples of channel 0 (a trailing partial frame counts for the FIR)
+        A.n_seg = (unsigned)((longest + A.seg_frames - 1) / A.seg_frames);
+        if (A.n_seg == 0) A.n_seg = 1;
+    }
+    A.sq_seg = 1u << 16;
+    A.n_sq_seg = (unsigned)((n + A.sq_seg - 1) / A.sq_seg);
+    {   // compute_true_peak's filter (ebu_r128.rs:117-140): 49-tap Hann-windowed sinc, designed at 4 fs, unit sum
+        const double oversample_rate = (double)sr * 4.0, cutoff = (double)sr * 0.45, center = 24.0;
+        double sum = 0.0;
+        for (int i = 0; i < 49; i++) {
+            const double nn = (double)i - center;
+            const double sinc = std::fabs(nn) < 1e-12 ? 2.0 * cutoff / oversample_rate : std::sin(2.0 * cutoff * nn / oversample_rate) / (M_PI * nn);
+            const double window = 0.5 * (1.0 - std::cos(2.0 * M_PI * (double)i / 48.0));
+            A.tp_coef[i] = sinc * window;
+        }
+        for (int i = 0; i < 49; i++) sum += A.tp_coef[i];
+        for (int i = 0; i < 49; i++) A.tp_coef[i] /= sum;
+    }
     A.n_chunks = (9ull + 4ull * n + 1023ull) / 1024ull;
     const uint64_t spc = n / ch;
     const uint64_t pts[3] = {spc / 4, spc / 2, spc * 3 / 4};
@@ -2172,22 +2215,28 @@ extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, 
         A.point_ok[i] = pts[i] + 256 < spc ? 1u : 0u;
     }
     // twiddles of the 256-point FFT: cos / sin in double, rounded to f32 (the values the oracle's FFT uses)
-    static float tw[8 * 128 * 2];
-    static bool have_tw = false;
-    if (!have_tw) {
+    // (a function-local static initialised by a lambda: thread-safe, contexts on several threads may meet here)
+    struct Tw {
+        float v[8 * 128 * 2];
+    };
+    static const Tw tw_table = [] {
+        Tw t{};
         for (int s = 0; s < 8; s++)
             for (int k = 0; k < (1 << s); k++) {
                 const double ang = -2.0 * M_PI * (double)k / (double)(2 << s);
-                tw[(s * 128 + k) * 2] = (float)std::cos(ang);
-                tw[(s * 128 + k) * 2 + 1] = (float)std::sin(ang);
+                t.v[(s * 128 + k) * 2] = (float)std::cos(ang);
+                t.v[(s * 128 + k) * 2 + 1] = (float)std::sin(ang);
             }
-        have_tw = true;
-    }
+        return t;
+    }();
+    const float (&tw)[8 * 128 * 2] = tw_table.v;
     // device buffers: pcm | results
     DevMem d_pcm, d_res, d_cvs;
+    QuiesceOnExit quiesce_d_pcm(c);
     HIPCHK(c, pool_alloc(&d_pcm.p, n * 4 + 64));
-    const size_t o_peaks = 0, o_sumsq = o_peaks + (((size_t)A.n_peaks * 4 + 15) & ~(size_t)15), o_blocks = o_sumsq + 16,
-                 o_tw = o_blocks + (((size_t)ch * A.n_blocks * 8 + 15) & ~(size_t)15), o_band = o_tw + sizeof tw, o_bin = o_band + 3 * 16 * 4,
+    const size_t o_peaks = 0, o_sumsq = o_peaks + (((size_t)A.n_peaks * 4 + 15) & ~(size_t)15),
+                 o_pk = o_sumsq + (((size_t)A.n_sq_seg * 4 + 15) & ~(size_t)15), o_blocks = o_pk + 16,
+                 o_tw = o_blocks + (((size_t)ch * A.n_blocks * 16 + 15) & ~(size_t)15), o_band = o_tw + sizeof tw, o_bin = o_band + 3 * 16 * 4,
                  res_bytes = o_bin + 3 * 8 * 4;
     HIPCHK(c, pool_alloc(&d_res.p, res_bytes + 64));
     HIPCHK(c, pool_alloc(&d_cvs.p, (2 * A.n_chunks + 1) * 32 + 64));
@@ -2203,8 +2252,9 @@ extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, 
     A.pcm = d_pcm.as<float>();
     char *rb = (char *)d_res.p;
     A.peaks = (float *)(rb + o_peaks);
-    A.sumsq = (float *)(rb + o_sumsq);
-    A.block_sums = (double *)(rb + o_blocks);
+    A.sumsq_part = (float *)(rb + o_sumsq);
+    A.peak_bits = (unsigned long long *)(rb + o_pk);
+    A.block_part = (double *)(rb + o_blocks);
     A.fft_tw = (const float *)(rb + o_tw);
     A.band_sqrt = (float *)(rb + o_band);
     A.peak_bin = (unsigned int *)(rb + o_bin);
@@ -2249,22 +2299,27 @@ extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, 
         for (int b = 0; b < 16; b++) mx = max_rust(mx, bands[b]);
         for (int b = 0; b < 16; b++) out->energy_profile[b] = mx > 0.f ? f32_as_u8(bands[b] / mx * 255.0f) : 0;
         memcpy(out->frequency_peaks, pk8, 8);
-        const float sumsq = *(const float *)(res.data() + o_sumsq);
+        float sumsq = 0.f;   // the segments' partial sums, in order (one segment: the reference's own sequential sum)
+        for (unsigned i = 0; i < A.n_sq_seg; i++) sumsq = i ? sumsq + ((const float *)(res.data() + o_sumsq))[i] : ((const float *)(res.data() + o_sumsq))[0];
         const float rms = sumsq / (float)n;
         float v = -20.0f * log10f(rms + 1e-10f);
         if (v == v) v = v < -60.0f ? -60.0f : (v > 0.0f ? 0.0f : v);
         out->avg_loudness = f32_as_u8(v + 60.0f);
     }
-    // integrated loudness: block energies summed over channels, then the two gates (ebu_r128.rs:236-318)
+    // loudness: block energies summed over channels, the two gates, the range of the gated block loudness and the two
+    // peaks (ebu_r128.rs:211-355)
     {
-        const double *bsum = (const double *)(res.data() + o_blocks);
+        const double *part = (const double *)(res.data() + o_blocks);
         std::vector<double> en(A.n_blocks);
         for (unsigned k = 0; k < A.n_blocks; k++) {
             double e = 0.0;
-            for (unsigned cc = 0; cc < ch; cc++) e += bsum[(size_t)cc * A.n_blocks + k] / (double)block_len[k];
+            for (unsigned cc = 0; cc < ch; cc++) {
+                const double *pp = part + ((size_t)cc * A.n_blocks + k) * 2;
+                e += (pp[0] + pp[1]) / (double)block_len[k];   // (a block inside one segment: x + 0.0, exact)
+            }
             en[k] = e;
         }
-        double lufs = -23.0;
+        double lufs = -23.0, lra = 0.0;
         if (!en.empty()) {
             const double abs_gate = std::pow(10.0, (-70.0 + 0.691) / 10.0);
             double sum = 0.0;
@@ -2278,16 +2333,33 @@ extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, 
                 const double ungated = -0.691 + 10.0 * std::log10(sum / (double)cnt);
                 const double rel_gate = std::pow(10.0, (ungated - 10.0 + 0.691) / 10.0);
                 double s2 = 0.0;
-                size_t c2 = 0;
+                std::vector<double> vals;
                 for (double e : en)
                     if (e >= abs_gate && e >= rel_gate) {
                         s2 += e;
-                        c2++;
+                        vals.push_back(e > 0.0 ? -0.691 + 10.0 * std::log10(e) : -150.0);
                     }
-                lufs = c2 ? -0.691 + 10.0 * std::log10(s2 / (double)c2) : ungated;
+                lufs = !vals.empty() ? -0.691 + 10.0 * std::log10(s2 / (double)vals.size()) : ungated;
+                if (vals.size() >= 2) {   // LRA: 10th - 95th percentile, linear interpolation (ebu_r128.rs:320-345)
+                    std::sort(vals.begin(), vals.end());
+                    const double nn = (double)vals.size();
+                    auto interp = [&](double pos) {
+                        const size_t i = (size_t)std::floor(pos);
+                        const double frac = pos - (double)i;
+                        return i + 1 < vals.size() ? vals[i] * (1.0 - frac) + vals[i + 1] * frac : vals[i];
+                    };
+                    lra = interp(0.95 * (nn - 1.0)) - interp(0.10 * (nn - 1.0));
+                }
             }
         }
         out->integrated_lufs = lufs;
+        out->loudness_range_lu = lra;
+        const unsigned long long *pb = (const unsigned long long *)(res.data() + o_pk);
+        double sp, tp;
+        memcpy(&sp, &pb[0], 8);
+        memcpy(&tp, &pb[1], 8);
+        out->sample_peak_dbfs = sp > 1e-6 ? 20.0 * std::log10(sp) : -150.0;
+        out->true_peak_dbtp = tp > 1e-9 ? 20.0 * std::log10(tp) : -150.0;
     }
     return FLO_OK;
 }

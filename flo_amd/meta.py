@@ -187,16 +187,95 @@ def _top_level(data: bytes) -> dict:
     return out
 
 
+# What serde accepts for each FloMetadata field (core/metadata.rs:328-665): the MessagePack type families. A value of
+# another family makes `from_slice::<FloMetadata>` fail, and lib.rs:228's `unwrap_or_default()` then drops ALL of the
+# caller's metadata; empty sequences and maps are skipped on re-serialisation (`skip_serializing_if = "...::is_empty"`).
+_STR = set("""title subtitle content_group album original_album set_subtitle isrc artist album_artist conductor remixer
+original_artist composer lyricist original_lyricist encoded_by genre mood key language recording_time release_time
+original_release_time encoding_time tagging_time copyright produced_notice publisher file_owner radio_station
+radio_station_owner album_sort artist_sort title_sort original_filename encoder_settings url_commercial url_copyright
+url_audio_file url_artist url_audio_source url_radio_station url_payment url_publisher flo_encoder_version
+source_format""".split())
+_U32 = set("track_number track_total disc_number disc_total bpm year playlist_delay".split())
+_U64 = set("length_ms play_count".split())
+_F32 = set("integrated_loudness_lufs loudness_range_lu true_peak_dbtp".split())
+_SEQ = set("""involved_people musician_credits user_urls comments lyrics synced_lyrics pictures user_text bpm_map key_changes
+loudness_profile section_markers creator_notes collaboration_credits remix_chain cover_variants""".split())
+_SEQ_SKIP_EMPTY = _SEQ - {"involved_people", "musician_credits"}      # those two are Option<Vec<..>>: Some(vec![]) is kept
+_STRUCT = set("popularimeter waveform_data animated_cover artist_signature".split())    # a map (named) or a sequence (compact)
+
+
+def _family(raw: bytes) -> str:
+    t = raw[0]
+    if t <= 0x7F or 0xCC <= t <= 0xCF:
+        return "uint"
+    if t >= 0xE0 or 0xD0 <= t <= 0xD3:
+        return "int"
+    if 0xA0 <= t <= 0xBF or t in (0xD9, 0xDA, 0xDB):
+        return "str"
+    if 0x90 <= t <= 0x9F or t in (0xDC, 0xDD):
+        return "seq"
+    if 0x80 <= t <= 0x8F or t in (0xDE, 0xDF):
+        return "map"
+    if t in (0xC4, 0xC5, 0xC6):
+        return "bin"
+    if t in (0xCA, 0xCB):
+        return "float"
+    if t in (0xC2, 0xC3):
+        return "bool"
+    return "nil" if t == 0xC0 else "other"
+
+
+def _field_ok(key: str, raw: bytes) -> bool:
+    fam = _family(raw)
+    if fam == "nil":
+        return True          # every field is an Option or has a default
+    if key in _STR:
+        return fam == "str"
+    if key in _U32 or key in _U64:
+        if fam == "int":
+            v = unpack(raw)
+            return isinstance(v, int) and v >= 0
+        if fam != "uint":
+            return False
+        return unpack(raw) < (1 << (32 if key in _U32 else 64))
+    if key in _F32:
+        return fam in ("float", "uint", "int")
+    if key in _SEQ:
+        return fam == "seq"
+    if key in _STRUCT:
+        return fam in ("map", "seq")
+    if key == "spectrum_fingerprint":
+        return fam in ("bin", "seq", "str")      # serde_bytes
+    if key == "custom":
+        return fam == "map"
+    return True
+
+
+def _is_empty(raw: bytes) -> bool:
+    return raw in (b"\x90", b"\x80", b"\xdc\x00\x00", b"\xdd\x00\x00\x00\x00", b"\xde\x00\x00", b"\xdf\x00\x00\x00\x00")
+
+
 def merge_analysis(user_meta: bytes, analysis_meta: bytes) -> bytes:
     """add_analysis_data_if_missing (lib.rs:219-283) for a caller who passes metadata of their own: the caller's fields
     stay (values re-emitted as they came), waveform_data / spectrum_fingerprint / loudness_profile are added only where
     missing, length_ms is always set; fields come out in FloMetadata's declaration order, unknown keys are dropped as
-    serde drops them, and undecodable input counts as empty (`unwrap_or_default`)."""
+    serde drops them, empty sequences / maps are skipped as `skip_serializing_if` skips them, and input serde would reject
+    (undecodable, or a known field of the wrong MessagePack type) counts as empty (`unwrap_or_default`). Values that
+    serde would re-encode in another form (an f64 where the field is f32, a non-minimal integer) are passed through as
+    they came."""
     fields = {}
     if user_meta:
         try:
-            fields = {k: v for k, v in _top_level(user_meta).items() if k in FIELD_ORDER and v != b"\xc0"}
-        except (ValueError, IndexError):
+            top = _top_level(user_meta)
+            if not all(isinstance(k, str) for k in top):
+                raise ValueError("a field name is not a string")
+            known = {k: v for k, v in top.items() if k in FIELD_ORDER}
+            if not all(_field_ok(k, v) for k, v in known.items()):
+                raise ValueError("a field has the wrong type: serde rejects the document, unwrap_or_default() takes over")
+            fields = {k: v for k, v in known.items()
+                      if v != b"\xc0" and not ((k in _SEQ_SKIP_EMPTY or k == "custom") and _is_empty(v))}
+        except (ValueError, IndexError, TypeError, struct.error):
             fields = {}
     an = _top_level(analysis_meta)
     if "waveform_data" not in fields:

@@ -191,6 +191,9 @@ typedef struct flo_analysis {
     uint8_t energy_profile[16];
     double integrated_lufs;
     uint64_t length_ms;
+    /* the rest of compute_ebu_r128_loudness (ebu_r128.rs:182-355; not part of the META chunk, printed by the CLI's
+     * `analysis` command like reflo's): range of the gated block loudness, the 49-tap "true peak", the sample peak */
+    double loudness_range_lu, true_peak_dbtp, sample_peak_dbfs;
 } flo_analysis;
 int flo_analyze(flo_ctx *ctx, const float *pcm, size_t n_interleaved, uint32_t sample_rate, uint8_t channels,
                 uint32_t peaks_per_second, float *peaks, size_t peaks_cap, flo_analysis *out);

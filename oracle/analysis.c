@@ -385,6 +385,157 @@ double flo_o_integrated_lufs(const float *samples, size_t len, uint8_t channels,
     return r;
 }
 
+/* compute_true_peak (ebu_r128.rs:112-179): a 49-tap Hann-windowed sinc (cutoff 0.45 fs, designed at 4 fs, normalised to
+ * unit sum) evaluated at the four sub-sample positions of every sample. The tap index is (pos - 24 + k) cast to usize -
+ * a floor - so the four positions of a sample read the SAME samples with the SAME taps: the result is the largest
+ * |output| of that FIR at the plain rate (the loop over `sub` is kept as the reference has it). */
+double flo_o_true_peak_dbtp(const float *samples, size_t len, uint8_t channels, uint32_t sample_rate) {
+    if (len == 0 || channels == 0) return -150.0;
+    const unsigned factor = 4;
+    const double oversample_rate = (double)sample_rate * (double)factor;
+    const double cutoff = (double)sample_rate * 0.45;
+    enum { TAPS = 49 };
+    double coeffs[TAPS];
+    const double center = (double)(TAPS - 1) / 2.0;
+    for (int i = 0; i < TAPS; i++) {
+        const double n = (double)i - center;
+        const double sinc = fabs(n) < 1e-12 ? 2.0 * cutoff / oversample_rate : sin(2.0 * cutoff * n / oversample_rate) / (M_PI * n);
+        const double window = 0.5 * (1.0 - cos(2.0 * M_PI * (double)i / (double)(TAPS - 1)));
+        coeffs[i] = sinc * window;
+    }
+    double sum = 0.0;
+    for (int i = 0; i < TAPS; i++) sum += coeffs[i];
+    for (int i = 0; i < TAPS; i++) coeffs[i] /= sum;
+    double max_peak = 0.0;
+    /* `samples.iter().skip(ch).step_by(channels)`: every channels-th value from ch on (a trailing partial frame counts) */
+    for (size_t ch = 0; ch < channels; ch++) {
+        const size_t n_ch = len > ch ? (len - ch + channels - 1) / channels : 0;
+        if (n_ch == 0) continue;
+        for (size_t i = 0; i < n_ch; i++)
+            for (unsigned sub = 0; sub < factor; sub++) {
+                const double pos = (double)i + (double)sub / (double)factor;
+                double acc = 0.0;
+                for (int k = 0; k < TAPS; k++) {
+                    const double src = pos - center + (double)k;
+                    if (src >= 0.0 && src < (double)n_ch) acc += (double)samples[(size_t)src * channels + ch] * coeffs[k];
+                }
+                if (fabs(acc) > max_peak) max_peak = fabs(acc);
+            }
+    }
+    return max_peak > 1e-9 ? 20.0 * log10(max_peak) : -150.0;
+}
+
+/* compute_ebu_r128_loudness (ebu_r128.rs:182-355): out = {integrated_lufs, loudness_range_lu, true_peak_dbtp,
+ * sample_peak_dbfs} */
+static int cmp_double(const void *a, const void *b) {
+    const double x = *(const double *)a, y = *(const double *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+void flo_o_loudness_metrics(const float *samples, size_t len, uint8_t channels, uint32_t sample_rate, double out[4]) {
+    out[0] = -23.0;
+    out[1] = 0.0;
+    out[2] = -150.0;
+    out[3] = -150.0;
+    if (len == 0 || channels == 0) return;
+    const double sr = (double)sample_rate;
+    const size_t hop = (size_t)round(sr * 0.1), block = hop * 4;
+    const size_t frames = len / channels;
+    /* sample peak: per channel, over whole frames */
+    double sample_peak = -150.0;
+    for (size_t c = 0; c < channels; c++) {
+        double peak = 0.0;
+        for (size_t i = 0; i < frames; i++) {
+            const double a = fabs((double)samples[i * channels + c]);
+            if (a > peak) peak = a;   /* f64::max ignores NaN the same way */
+        }
+        if (peak > 1e-6) {
+            const double db = 20.0 * log10(peak);
+            if (db > sample_peak) sample_peak = db;
+        }
+    }
+    out[3] = sample_peak;
+    double shelf[5], hp[5];
+    flo_o_kweighting_coeffs(sr, shelf, hp);
+    double *kw = (double *)malloc((frames ? frames : 1) * channels * sizeof(double));
+    for (size_t c = 0; c < channels; c++) {
+        double s1 = 0, s2 = 0, h1 = 0, h2 = 0;
+        for (size_t i = 0; i < frames; i++) {
+            double x = (double)samples[i * channels + c];
+            double y = shelf[0] * x + s1;
+            s1 = shelf[1] * x - shelf[3] * y + s2;
+            s2 = shelf[2] * x - shelf[4] * y;
+            double y2 = hp[0] * y + h1;
+            h1 = hp[1] * y - hp[3] * y2 + h2;
+            h2 = hp[2] * y - hp[4] * y2;
+            kw[c * frames + i] = y2;
+        }
+    }
+    double *en = NULL, *bl = NULL;
+    size_t nb = 0, capb = 0, start = 0;
+    while (start < frames) {
+        size_t end = start + block < frames ? start + block : frames;
+        if (end <= start) break;
+        double energy = 0.0;
+        const size_t l = end - start;
+        for (size_t c = 0; c < channels; c++) {
+            double ss = 0.0;
+            for (size_t i = start; i < end; i++) ss += kw[c * frames + i] * kw[c * frames + i];
+            energy += ss / (double)l;
+        }
+        if (nb == capb) {
+            capb = capb ? 2 * capb : 64;
+            en = (double *)realloc(en, capb * sizeof(double));
+            bl = (double *)realloc(bl, capb * sizeof(double));
+        }
+        en[nb] = energy;
+        bl[nb] = energy > 0.0 ? -0.691 + 10.0 * log10(energy) : -150.0;
+        nb++;
+        if (end == frames) break;
+        start += hop;
+        if (hop == 0) break;
+    }
+    free(kw);
+    out[2] = flo_o_true_peak_dbtp(samples, len, channels, sample_rate);
+    if (nb) {
+        const double abs_gate = pow(10.0, (-70.0 + 0.691) / 10.0);
+        double sum = 0.0;
+        size_t cnt = 0;
+        for (size_t i = 0; i < nb; i++)
+            if (en[i] >= abs_gate) {
+                sum += en[i];
+                cnt++;
+            }
+        if (cnt) {
+            const double ungated = -0.691 + 10.0 * log10(sum / (double)cnt);
+            const double rel_gate = pow(10.0, (ungated - 10.0 + 0.691) / 10.0);
+            double *vals = (double *)malloc(nb * sizeof(double));
+            double s2 = 0.0;
+            size_t c2 = 0;
+            for (size_t i = 0; i < nb; i++)
+                if (en[i] >= abs_gate && en[i] >= rel_gate) {
+                    s2 += en[i];
+                    vals[c2++] = bl[i];
+                }
+            out[0] = c2 == 0 ? ungated : -0.691 + 10.0 * log10(s2 / (double)c2);
+            if (c2 >= 2) {   /* LRA: 10th - 95th percentile of the gated block loudness, linear interpolation */
+                qsort(vals, c2, sizeof(double), cmp_double);
+                const double n = (double)c2;
+                const double pos[2] = {0.10 * (n - 1.0), 0.95 * (n - 1.0)};
+                double pv[2];
+                for (int q = 0; q < 2; q++) {
+                    const size_t i = (size_t)floor(pos[q]);
+                    const double frac = pos[q] - (double)i;
+                    pv[q] = i + 1 < c2 ? vals[i] * (1.0 - frac) + vals[i + 1] * frac : vals[i];
+                }
+                out[1] = pv[1] - pv[0];
+            }
+            free(vals);
+        }
+    }
+    free(en);
+    free(bl);
+}
+
 /* ------------------------------------------------------------------ MessagePack (named maps) */
 static void mp_uint(flo_buf *b, uint64_t v) {
     if (v < 128) buf_push(b, (uint8_t)v);

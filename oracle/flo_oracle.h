@@ -121,6 +121,9 @@ void flo_o_spectral_fingerprint(const float *samples, size_t len, uint8_t channe
 void flo_o_kweighting_coeffs(double sample_rate, double shelf[5], double hp[5]);      /* ebu_r128.rs:51-103 */
 double flo_o_gated_lufs(const double *energies, size_t n);                            /* ebu_r128.rs:268-318 */
 double flo_o_integrated_lufs(const float *samples, size_t len, uint8_t channels, uint32_t sample_rate); /* :182-318 */
+double flo_o_true_peak_dbtp(const float *samples, size_t len, uint8_t channels, uint32_t sample_rate); /* ebu_r128.rs:112-179 */
+/* out = {integrated_lufs, loudness_range_lu, true_peak_dbtp, sample_peak_dbfs}                   ebu_r128.rs:182-355 */
+void flo_o_loudness_metrics(const float *samples, size_t len, uint8_t channels, uint32_t sample_rate, double out[4]);
 /* add_analysis_data_if_missing(&[], samples, sr, ch, peaks_per_second): the META bytes (lib.rs:219-283) */
 int flo_o_analysis_metadata(const float *samples, size_t len, uint32_t sample_rate, uint8_t channels,
                             uint32_t peaks_per_second, uint8_t **out, size_t *out_len);

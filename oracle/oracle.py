@@ -331,6 +331,17 @@ def integrated_lufs(pcm, channels, sample_rate) -> float:
     return L.flo_o_integrated_lufs(p.ctypes.data, p.size, channels, sample_rate)
 
 
+def loudness_metrics(pcm, channels, sample_rate) -> dict:
+    """compute_ebu_r128_loudness (ebu_r128.rs:182-355)"""
+    L = lib()
+    L.flo_o_loudness_metrics.restype = None
+    L.flo_o_loudness_metrics.argtypes = [C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint32, C.POINTER(C.c_double)]
+    p = np.ascontiguousarray(pcm, np.float32).ravel()
+    out = (C.c_double * 4)()
+    L.flo_o_loudness_metrics(p.ctypes.data, p.size, channels, sample_rate, out)
+    return dict(integrated_lufs=out[0], loudness_range_lu=out[1], true_peak_dbtp=out[2], sample_peak_dbfs=out[3])
+
+
 def analysis_metadata(pcm, sample_rate, channels, peaks_per_second=50) -> bytes:
     """add_analysis_data_if_missing(&[], ...) (lib.rs:219-283): the META bytes libflo::encode* build"""
     L = lib()

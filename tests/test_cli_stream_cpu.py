@@ -147,3 +147,31 @@ def test_meta_chunk_of_every_reference_made_file_is_reproduced():
         assert rebuilt == chunk, (f, rebuilt, chunk)
     assert meta.encoder_settings(True, 0.6, 192, 5) == "Lossy, target 192kbps"
     assert meta.unpack(meta.pack_fields(dict(title="T" * 40, artist="A", album=None, length_ms=70000))) == {"title": "T" * 40, "artist": "A", "length_ms": 70000}
+
+
+def test_merge_analysis_follows_serde_on_malformed_caller_metadata():
+    # lib.rs:228: from_slice::<FloMetadata>(metadata).unwrap_or_default() - one field of the wrong type and ALL of the
+    # caller's metadata is gone; empty sequences are skipped on the way out; unknown keys are dropped
+    from flo_amd import meta
+    an = (b"\x84" + meta._str("length_ms") + b"\xcd\x03\xe8" + meta._str("waveform_data") + b"\x80"
+          + meta._str("spectrum_fingerprint") + b"\xc4\x01\x07" + meta._str("loudness_profile") + b"\x91\x80")
+    names = lambda b: list(meta.unpack(b))      # noqa: E731
+    ok = b"\x82" + meta._str("title") + meta._str("Song") + meta._str("track_number") + b"\x03"
+    assert names(meta.merge_analysis(ok, an)) == ["title", "track_number", "length_ms", "waveform_data", "spectrum_fingerprint", "loudness_profile"]
+    # title as an integer: serde rejects the document
+    bad = b"\x82" + meta._str("title") + b"\x05" + meta._str("album") + meta._str("LP")
+    assert names(meta.merge_analysis(bad, an)) == ["length_ms", "waveform_data", "spectrum_fingerprint", "loudness_profile"]
+    # a negative track number, a float where a string belongs, a string where a sequence belongs
+    for raw in (meta._str("track_number") + b"\xff", meta._str("artist") + b"\xca\x00\x00\x00\x00", meta._str("comments") + meta._str("x")):
+        assert names(meta.merge_analysis(b"\x82" + meta._str("album") + meta._str("LP") + raw, an)) == \
+            ["length_ms", "waveform_data", "spectrum_fingerprint", "loudness_profile"]
+    # empty Vec fields disappear, an empty custom map too; an unknown key is dropped; nil is "not set"
+    doc = (b"\x85" + meta._str("album") + meta._str("LP") + meta._str("comments") + b"\x90" + meta._str("custom") + b"\x80"
+           + meta._str("not_a_field") + b"\x01" + meta._str("genre") + b"\xc0")
+    assert names(meta.merge_analysis(doc, an)) == ["album", "length_ms", "waveform_data", "spectrum_fingerprint", "loudness_profile"]
+    # a key that is not a string (here an array): rejected, not a crash
+    assert names(meta.merge_analysis(b"\x81\x91\x01\x02", an)) == ["length_ms", "waveform_data", "spectrum_fingerprint", "loudness_profile"]
+    # the caller's own analysis fields win, except an empty loudness profile
+    own = b"\x82" + meta._str("waveform_data") + b"\x81" + meta._str("x") + b"\x01" + meta._str("loudness_profile") + b"\x90"
+    m = meta.unpack(meta.merge_analysis(own, an))
+    assert m["waveform_data"] == {"x": 1} and m["loudness_profile"] == [{}]

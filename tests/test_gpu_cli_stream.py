@@ -90,3 +90,28 @@ def test_streaming_encoder_equals_the_oracles(ctx, sr, ch, level):
     assert (fg.index, fg.timestamp_ms, fg.samples, fg.data) == (fo["index"], fo["timestamp_ms"], fo["samples"], fo["data"])
     assert g.pending_frames() == 0 and g.finalize() == o.finalize()
     g.close()
+
+
+def test_cli_analysis_command(ctx, tmp_path, capsys):
+    # reflo's `analysis` sub-command (reflo/src/main.rs:619-800) on a reference-made file: the numbers are flo_analyze's
+    # (device) on the decoded samples and equal the oracle's restatement of compute_ebu_r128_loudness
+    import json
+    from flo_amd import cli
+    from oracle import oracle as O
+    src = example_bytes("chord_cmajor_stereo.flo")
+    p = tmp_path / "c.flo"
+    p.write_bytes(src)
+    assert cli.main(["analysis", str(p), "--waveform", "--spectrum", "--json"]) == 0
+    rep = json.loads(capsys.readouterr().out)
+    pcm, sr, ch = O.decode(src)
+    o = O.loudness_metrics(pcm, ch, sr)
+    one_segment = pcm.size // ch <= 65536
+    for k, v in o.items():
+        assert rep["loudness"][k] == v if one_segment else abs(rep["loudness"][k] - v) <= 1e-9 * max(1.0, abs(v)), k
+    assert rep["file_info"]["sample_rate"] == sr and rep["file_info"]["channels"] == ch
+    fp = O.spectral_fingerprint(pcm, ch, sr)
+    assert rep["spectral"]["spectral_hash_hex"] == fp["hash"][:8].hex() and rep["spectral"]["energy_profile"] == list(fp["energy_profile"])
+    assert rep["waveform"]["total_peaks"] == O.waveform_peaks(pcm, ch, sr, 60).size and rep["waveform"]["peaks_per_second"] == 60
+    assert cli.main(["analysis", str(p)]) == 0
+    text = capsys.readouterr().out
+    assert "Loudness Metrics (EBU R128)" in text and "Integrated loudness:" in text and "True peak:" in text

@@ -124,3 +124,27 @@ def test_meta_layout_and_merge():
     assert list(merged) == ["title", "artist", "length_ms", "waveform_data", "spectrum_fingerprint", "loudness_profile"]
     assert merged["title"] == "T" and merged["length_ms"] == d["length_ms"]
     assert meta.merge_analysis(b"", m) == m and meta.merge_analysis(b"\\xff garbage", m) == m
+
+
+# ---- the reference's own property checks (tests/analysis_cases.py), applied to the oracle ------------------------------
+import pytest  # noqa: E402
+import analysis_cases as AC  # noqa: E402
+
+
+@pytest.mark.parametrize("name,pcm,ch,sr,check", list(AC.loudness_cases()), ids=[c[0] for c in AC.loudness_cases()])
+def test_reference_loudness_bars_hold_for_the_oracle(name, pcm, ch, sr, check):
+    m = O.loudness_metrics(pcm, ch, sr)
+    check(m)
+    assert m == O.loudness_metrics(pcm, ch, sr)                       # loudness_tests.rs:167-177
+    assert m["integrated_lufs"] == O.integrated_lufs(pcm, ch, sr)     # the META path's own function agrees
+
+
+def test_reference_waveform_and_fingerprint_bars_hold_for_the_oracle():
+    AC.check_waveform_peaks(lambda s, ch, sr, pps: O.waveform_peaks(s, ch, sr, pps))
+
+    def fp(s, ch, sr):
+        d = dict(O.spectral_fingerprint(s, ch, sr))
+        d.setdefault("channels", ch)
+        d.setdefault("sample_rate", sr)
+        return d
+    AC.check_fingerprint(fp)
