@@ -723,6 +723,31 @@ static int batch_sync_impl(flo_batch *b, hipEvent_t done) {
                     fprintf(stderr, " | T waits>1000: %.2f%% of frames, %.0f cyc/frame avg; >5000: %.2f%%, %.0f | P busy>12000: %.2f%%, %.0f; >20000: %.2f%%, %.0f\n",
                             100 * t[10] / b->total_frames, t[9] / b->total_frames, 100 * t[12] / b->total_frames, t[11] / b->total_frames,
                             100 * p[10] / b->total_frames, p[9] / b->total_frames, 100 * p[12] / b->total_frames, p[11] / b->total_frames);
+                    // per clip: the packer's busy ticks per frame against the transform's (who waits for whom is a property
+                    // of the clip's content): deciles over the clips
+                    std::vector<double> pb(b->n_clips), tb(b->n_clips);
+                    for (size_t k = 0; k < b->n_clips; k++) {
+                        const double fr = (double)b->hops[k] > 0 ? (double)b->hops[k] : 1.0;
+                        double tq = 0, pq = 0;
+                        for (int i = 0; i < 9; i++) if (i != 7) tq += (double)st[(2 * k) * 16 + i];
+                        for (int i = 1; i < 5; i++) pq += (double)st[(2 * k + 1) * 16 + i];
+                        tb[k] = tq / fr; pb[k] = pq / fr;
+                    }
+                    if (const char *dump = getenv("FLO_STAMPS_DUMP")) {   // raw per-clip records for diag/stamps_clips.py
+                        if (FILE *fh = fopen(dump, "wb")) {
+                            fwrite(st.data(), 8, st.size(), fh);
+                            fclose(fh);
+                        }
+                    }
+                    std::vector<double> ps = pb, ts = tb;
+                    std::sort(ps.begin(), ps.end()); std::sort(ts.begin(), ts.end());
+                    fprintf(stderr, "[stamps2x] per-clip busy ticks per frame, deciles | P:");
+                    for (int d = 0; d <= 10; d++) fprintf(stderr, " %.0f", ps[std::min(b->n_clips - 1, (size_t)(d * (b->n_clips - 1) / 10))]);
+                    fprintf(stderr, " | T:");
+                    for (int d = 0; d <= 10; d++) fprintf(stderr, " %.0f", ts[std::min(b->n_clips - 1, (size_t)(d * (b->n_clips - 1) / 10))]);
+                    size_t pbound = 0;
+                    for (size_t k = 0; k < b->n_clips; k++) pbound += pb[k] > tb[k];
+                    fprintf(stderr, " | clips whose packer is busier than their transform: %.1f%%\n", 100.0 * pbound / b->n_clips);
                 }
                 static const char *nm[] = {"wait-loads+fold", "issue-loads", "fft", "postrot", "analyse(bands,psy,quant,plan)",
                                            "sync-tot", "emit", "sync-emit", "flush", "sync-tail"};

@@ -1263,46 +1263,55 @@ __device__ __forceinline__ uint32_t sparse_block_pack(const int lane, const uint
     const uint32_t pos_l = (uint32_t)(2 * lane);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const uint32_t lo = xd[k] & 0xFFFFu, hi = xd[k] >> 16;
-        const unsigned long long E = __ballot(lo != 0u), O = __ballot(hi != 0u);
+        // ballots of the even (low halfword) and odd (high halfword) positions: a 16-bit compare reads the low half only
+        unsigned long long E;
+        asm("v_cmp_ne_u16_e64 %0, 0, %1" : "=s"(E) : "v"(xd[k]));
+        const unsigned long long O = __ballot(xd[k] > 0xFFFFu);
         const unsigned long long any = E | O;
         if (any == 0ull) {   // uniform: 128 zeros
             cz += 128u;
             carry = 0;
             continue;
         }
-        {   // zeros in front of the block's first non-zero: a two-byte varint shifts everything from here on by one byte
-            const uint32_t fe = E ? 2u * (uint32_t)__builtin_ctzll(E) : 999u, fo = O ? 2u * (uint32_t)__builtin_ctzll(O) + 1u : 999u;
-            const uint32_t f = fe < fo ? fe : fo;
-            W += cz + f >= 128u ? 1u : 0u;
+        {   // zeros in front of the block's first non-zero, f = 2 t + (even position of pair t non-zero ? 0 : 1): a two-byte
+            // varint (cz + f >= 128) shifts everything from here on by one byte
+            uint32_t t, nf;
+            asm("s_ff1_i32_b64 %0, %2\n\ts_bitcmp1_b64 %3, %0\n\ts_cselect_b32 %1, 0, 1" : "=&s"(t), "=s"(nf) : "s"(any), "s"(E) : "scc");
+            W += cz + 2u * t + nf >= 128u ? 1u : 0u;
         }
         const unsigned long long S_lo = E & ~((O << 1) | carry), S_hi = O & ~E, S = S_lo | S_hi;
         carry = O >> 63;
-        {
-            const uint32_t top = 63u - (uint32_t)__builtin_clzll(any);
-            cz = 127u - (2u * top + (uint32_t)((O >> top) & 1ull));
+        {   // zeros behind the block's last non-zero: 2 clz(any) + (odd position of the top pair non-zero ? 0 : 1)
+            uint32_t fl, nb;
+            asm("s_flbit_i32_b64 %0, %2\n\ts_sub_u32 %1, 63, %0\n\ts_bitcmp1_b64 %3, %1\n\ts_cselect_b32 %1, 0, 1"
+                : "=&s"(fl), "=&s"(nb) : "s"(any), "s"(O) : "scc");
+            cz = 2u * fl + nb;
         }
         const uint32_t nzb = __builtin_amdgcn_mbcnt_hi((uint32_t)(O >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)O, mbcnt64(E)));
-        const uint32_t stb = __builtin_amdgcn_mbcnt_hi((uint32_t)(S_hi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)S_hi, mbcnt64(S_lo)));
+        // a lane starts at most one run (S_lo needs E, S_hi needs ~E): one count over S serves both halves
+        const uint32_t stb = mbcnt64(S);
+        uint32_t slo, shi;
+        asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(slo) : "s"(S_lo));
+        asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(shi) : "s"(S_hi));
         // byte address of the lane's even-position value: 2 (items in front of it) + blob + W; the header of a run that
         // starts on the even position is one of those items
-        const uint32_t slo = (uint32_t)((S_lo >> lane) & 1ull);
         const uint32_t a = ((nzb + stb + slo) << 1) + (blob + W + 2u * (nM + nS));
         // run table: slot 1 + (runs in front), entry (rank of the run's first non-zero) << 16 | position
         uint32_t ta = (stb << 2) + (tab + 4u * (nS + 1u));
         ta = ta < tmax ? ta : tmax;
-        const uint32_t shi = (uint32_t)((S_hi >> lane) & 1ull);
-        const uint32_t ent = ((nzb + nM) << 16) | (pos_l + (uint32_t)(128 * k) + shi);
+        const uint32_t ent = (nzb << 16) + ((nM << 16) + (uint32_t)(128 * k)) + (pos_l + shi);
         {
-            const uint32_t lo8 = lo >> 8, hi8 = hi >> 8;
+            // bytes: low halfword from bits 0..7 of the dword and of the dword >> 8, high halfword from bits 16..23 of the same
+            // two registers (ds_write_b8_d16_hi)
+            const uint32_t x8 = xd[k] >> 8;
             unsigned long long sv;
             asm volatile("s_mov_b64 %0, exec\n\t"
                          "s_mov_b64 exec, %1\n\tds_write_b8 %4, %5\n\tds_write_b8 %4, %6 offset:1\n\t"
-                         "s_mov_b64 exec, %2\n\tds_write_b8 %4, %7 offset:2\n\tds_write_b8 %4, %8 offset:3\n\t"
-                         "s_mov_b64 exec, %3\n\tds_write_b32 %9, %10\n\t"
+                         "s_mov_b64 exec, %2\n\tds_write_b8_d16_hi %4, %5 offset:2\n\tds_write_b8_d16_hi %4, %6 offset:3\n\t"
+                         "s_mov_b64 exec, %3\n\tds_write_b32 %7, %8\n\t"
                          "s_mov_b64 exec, %0"
                          : "=&s"(sv)
-                         : "s"(E), "s"(O), "s"(S), "v"(a), "v"(lo), "v"(lo8), "v"(hi), "v"(hi8), "v"(ta), "v"(ent));
+                         : "s"(E), "s"(O), "s"(S), "v"(a), "v"(xd[k]), "v"(x8), "v"(ta), "v"(ent));
         }
         nM += (uint32_t)__builtin_popcountll(E) + (uint32_t)__builtin_popcountll(O);
         nS += (uint32_t)__builtin_popcountll(S);

@@ -884,22 +884,22 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
                     t = P[0].total;
                 }
                 tot[ch] = t;
-                if (ln == 32 + ch) {
-                    uint8_t *p = f + pos;
-                    p[0] = (uint8_t)t; p[1] = (uint8_t)(t >> 8); p[2] = (uint8_t)(t >> 16); p[3] = (uint8_t)(t >> 24);
-                }
                 pos += 4u + t;
                 STAMP(2 + ch);
             }
             const uint32_t flen = pos, blob_len = flen - 10;
-            if (ln == 0) {
-                f[0] = 253;
-                f[1] = 0x00; f[2] = 0x04; f[3] = 0; f[4] = 0;  // frame_samples = 1024
-                f[5] = 0;
-                f[6] = (uint8_t)blob_len; f[7] = (uint8_t)(blob_len >> 8); f[8] = (uint8_t)(blob_len >> 16); f[9] = (uint8_t)(blob_len >> 24);
-                f[10] = 0;  // BlockSize::Long
-                f[11] = 2;
-                A.frame_size[frame0 + h] = flen;
+            {
+                // the 12 header bytes [253][frame_samples = 1024 u32][0][blob_len u32][BlockSize::Long = 0][2 channels] and the
+                // two channel length words as ONE byte store: lane i < 12 holds header byte i, lanes 12..15 / 16..19 the bytes
+                // of the first / second length word (twenty single-lane byte stores and three exec branches before)
+                const uint32_t i = (uint32_t)ln;
+                const uint32_t w0 = 0x000400FDu, w1 = blob_len << 16, w2 = (blob_len >> 16) | 0x02000000u;
+                uint32_t wv = i < 4u ? w0 : (i < 8u ? w1 : w2);
+                wv = i < 12u ? wv : (i < 16u ? tot[0] : tot[1]);
+                uint32_t off = i < 12u ? i : (i < 16u ? 112u - 12u + i : 116u - 16u + tot[0] + i);
+                const uint32_t bv = wv >> (8u * (i & 3u));
+                if (i < 20u) lds_st8<0>(f + off, bv);
+                if (ln == 0) A.frame_size[frame0 + h] = flen;
             }
             wave_sync();
             // has the transform wave published the next frame meanwhile? (asked before the flush, needed after it)
@@ -930,7 +930,11 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         if (lane == 0) A.clip_bytes[clip] = written + pend;
 #ifdef FLO_STAMPS
         if (A.dbg_stamps && lane == 0)
+        {
+            st_sum[13] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+                         ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32) | ((unsigned long long)cl << 40);
             for (int i = 0; i < 14; i++) A.dbg_stamps[((unsigned long long)clip * 2 + 1) * 16 + i] = st_sum[i];
+        }
 #endif
         fbase += hops;
         continue;
@@ -1075,7 +1079,11 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
     }
 #ifdef FLO_STAMPS
     if (A.dbg_stamps && lane == 0)
+    {   // [13]: where the wave ran (HW_ID, XCC_ID, clip slot): diag/stamps_clips.py groups the records by it
+        st_sum[13] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+                     ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32) | ((unsigned long long)cl << 40);
         for (int i = 0; i < 14; i++) { A.dbg_stamps[((unsigned long long)clip * 2) * 16 + i] = st_sum[i]; st_sum[i] = 0; }
+    }
 #endif
     fbase += hops;
     }   // next clip
