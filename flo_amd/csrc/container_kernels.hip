@@ -155,23 +155,31 @@ __global__ __launch_bounds__(kFinThreads) void crc_slices_kernel(FinishArgs A) {
     }
 }
 
-// THREADS: 256 for batches of many clips, 1024 for a few long ones (a 3-minute clip has 7752 TOC entries: at 256 threads a
-// thread wrote 31 of them one after the other and the kernel took 35 us by itself)
+// THREADS: 256 for batches of many clips, 1024 for a few long ones. The TOC of a long clip is cut into chunks of
+// A.toc_chunk frames, one workgroup each (blockIdx.y): a 3-minute clip has 7752 entries, and one workgroup writing all
+// of them was 20-28 us of a 0.15 ms encode. A chunk's workgroup first adds up the sizes in front of its chunk (strided
+// loads, a block reduction), then scans its own frames; chunk 0 also joins the CRC slices and writes the header, the
+// last chunk the header's total_samples.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void finish_files_kernel(FinishArgs A) {
     __shared__ uint32_t s_red[THREADS / 64];
-    __shared__ unsigned long long s_sum[THREADS];
-    __shared__ unsigned long long s_smp[THREADS];
+    __shared__ unsigned long long w_sum[THREADS / 64], w_smp[THREADS / 64], p_sum[THREADS / 64], p_smp[THREADS / 64];
     const unsigned clip = blockIdx.x;
     if (clip >= (unsigned)A.n_clips) return;
-    const unsigned t = threadIdx.x;
+    const unsigned t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const unsigned nf = A.clip_frames[clip];
+    const unsigned chunk = A.toc_chunk ? A.toc_chunk : 0xFFFFFFFFu;
+    const unsigned long long c0l = (unsigned long long)blockIdx.y * chunk;
+    if (c0l >= nf && blockIdx.y != 0) return;   // (an empty clip still gets its header from chunk 0)
+    const unsigned c0 = (unsigned)(c0l < nf ? c0l : nf), c1 = (unsigned)(c0l + chunk < nf ? c0l + chunk : nf);
+    const bool first = blockIdx.y == 0, last = c1 == nf;
     const unsigned long long n = A.clip_bytes[clip];
     uint8_t *file = A.out + A.data_off[clip] - (74ull + 20ull * nf);
+    const unsigned long long fb = A.clip_frame0[clip];
 
     // slice registers -> end of the message; thread `parts` adds the initial register carried through all n bytes
     uint32_t acc = 0;
-    {
+    if (first) {
         const unsigned long long S = slice_bytes(n, A.parts);
         if (t < A.parts) {
             const unsigned long long end = (unsigned long long)(t + 1) * S < n ? (unsigned long long)(t + 1) * S : n;
@@ -180,47 +188,90 @@ __global__ __launch_bounds__(THREADS) void finish_files_kernel(FinishArgs A) {
         } else if (t == A.parts) {
             acc = multmodp(x8n_fast(A, n), 0xFFFFFFFFu);
         }
+        for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_down(acc, d);
+        if (lane == 0) s_red[wv] = acc;
     }
-    for (int d = 32; d > 0; d >>= 1) acc ^= __shfl_down(acc, d);
-    if ((t & 63) == 0) s_red[t >> 6] = acc;
 
-    // TOC: thread t owns a contiguous run of frames; byte offsets and sample counts by a block scan of the run sums
-    const unsigned per = (nf + THREADS - 1) / THREADS;
-    const unsigned f0 = t * per < nf ? t * per : nf, f1 = f0 + per < nf ? f0 + per : nf;
-    const unsigned long long fb = A.clip_frame0[clip];
+    // bytes and samples in front of the chunk
+    unsigned long long pb = 0, ps = 0;
+    for (unsigned f = t; f < c0; f += 4 * THREADS) {
+        uint32_t a4[4], b4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned g = f + j * THREADS;
+            a4[j] = g < c0 ? A.frame_size[fb + g] : 0u;
+            b4[j] = g < c0 ? (A.frame_samples ? A.frame_samples[fb + g] : A.const_samples) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { pb += a4[j]; ps += b4[j]; }
+    }
+    // TOC: thread t owns a contiguous run of the chunk's frames; byte offsets and sample counts by a block scan of the run
+    // sums (wave scans by shuffles, the wave totals by the first wave: two barriers instead of the twenty of a
+    // Hillis-Steele scan). The run's sizes and sample counts are fetched eight independent loads at a time (a loop of
+    // single loads pays one memory latency per frame); the first eight stay in registers for the entries written below.
+    const unsigned per = (c1 - c0 + THREADS - 1) / THREADS;
+    const unsigned f0 = c0 + t * per < c1 ? c0 + t * per : c1, f1 = f0 + per < c1 ? f0 + per : c1;
     unsigned long long bytes = 0, smp = 0;
-    for (unsigned f = f0; f < f1; f++) {
-        bytes += A.frame_size[fb + f];
-        smp += A.frame_samples ? A.frame_samples[fb + f] : A.const_samples;
+    uint32_t kfs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ksm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (unsigned fbb = f0; fbb < f1; fbb += 8) {
+        uint32_t a8[8], b8[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            a8[j] = fbb + j < f1 ? A.frame_size[fb + fbb + j] : 0u;
+            b8[j] = fbb + j < f1 ? (A.frame_samples ? A.frame_samples[fb + fbb + j] : A.const_samples) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { bytes += a8[j]; smp += b8[j]; }
+        if (fbb == f0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { kfs[j] = a8[j]; ksm[j] = b8[j]; }
+        }
     }
-    s_sum[t] = bytes;
-    s_smp[t] = smp;
+    unsigned long long sb = bytes, ss = smp;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long ub = __shfl_up(sb, d), us = __shfl_up(ss, d);
+        if (lane >= (unsigned)d) { sb += ub; ss += us; }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { pb += __shfl_down(pb, d); ps += __shfl_down(ps, d); }
+    if (lane == 63) { w_sum[wv] = sb; w_smp[wv] = ss; }
+    if (lane == 0) { p_sum[wv] = pb; p_smp[wv] = ps; }
     __syncthreads();
-    for (int d = 1; d < THREADS; d <<= 1) {   // inclusive Hillis-Steele scans
-        const unsigned long long a = t >= (unsigned)d ? s_sum[t - d] : 0, b = t >= (unsigned)d ? s_smp[t - d] : 0;
-        __syncthreads();
-        s_sum[t] += a;
-        s_smp[t] += b;
-        __syncthreads();
+    if (wv == 0) {
+        unsigned long long xb = lane < THREADS / 64 ? w_sum[lane] : 0, xs = lane < THREADS / 64 ? w_smp[lane] : 0;
+        unsigned long long qb = lane < THREADS / 64 ? p_sum[lane] : 0, qs = lane < THREADS / 64 ? p_smp[lane] : 0;
+#pragma unroll
+        for (int d = 1; d < THREADS / 64; d <<= 1) {
+            const unsigned long long ub = __shfl_up(xb, d), us = __shfl_up(xs, d);
+            if (lane >= (unsigned)d) { xb += ub; xs += us; }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { qb += __shfl_down(qb, d); qs += __shfl_down(qs, d); }
+        if (lane < THREADS / 64) { w_sum[lane] = xb; w_smp[lane] = xs; }
+        if (lane == 0) { p_sum[0] = qb; p_smp[0] = qs; }
     }
+    __syncthreads();
+    if (wv) { sb += w_sum[wv - 1]; ss += w_smp[wv - 1]; }
+    sb += p_sum[0];
+    ss += p_smp[0];
     {
-        unsigned long long off = s_sum[t] - bytes, cum = s_smp[t] - smp;
+        unsigned long long off = sb - bytes, cum = ss - smp;
         // The DATA chunk is 16-byte aligned and the TOC ends right in front of it, 20 bytes per entry: every entry is
         // 4-byte aligned, five dword stores. The timestamp floor(cum * 1000 / rate) is carried as quotient and
         // remainder from entry to entry (one 64-bit division per thread, 32-bit ones after it where they suffice).
         uint32_t *toc = reinterpret_cast<uint32_t *>(file + 70 + 4);
         const unsigned long long rate = A.sample_rate;
         unsigned long long q = cum * 1000ull / rate, r = cum * 1000ull - q * rate;
-        for (unsigned f = f0; f < f1; f++) {   // writer.rs:193-224: index, byte offset, size, timestamp in ms
+        auto entry = [&](const unsigned f, const unsigned fs, const unsigned nsmp) {   // writer.rs:193-224: index, byte offset, size, timestamp in ms
             uint32_t *e = toc + 5ull * f;
-            const unsigned fs = A.frame_size[fb + f];
             e[0] = f;
             e[1] = (uint32_t)off;
             e[2] = (uint32_t)(off >> 32);
             e[3] = fs;
             e[4] = (uint32_t)q;
             off += fs;
-            const unsigned long long add = (unsigned long long)(A.frame_samples ? A.frame_samples[fb + f] : A.const_samples) * 1000ull + r;
+            const unsigned long long add = (unsigned long long)nsmp * 1000ull + r;
             if (add < 0x100000000ull) {
                 const uint32_t a32 = (uint32_t)add, r32 = (uint32_t)rate, dq = a32 / r32;
                 q += dq;
@@ -230,9 +281,14 @@ __global__ __launch_bounds__(THREADS) void finish_files_kernel(FinishArgs A) {
                 q += dq;
                 r = add - dq * rate;
             }
-        }
+        };
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (f0 + j < f1) entry(f0 + j, kfs[j], ksm[j]);
+        for (unsigned f = f0 + 8; f < f1; f++) entry(f, A.frame_size[fb + f], A.frame_samples ? A.frame_samples[fb + f] : A.const_samples);
     }
-    if (t == 0) {
+    if (last && t == 0) put64(file + 14, w_smp[THREADS / 64 - 1] + p_smp[0]);   // total_samples = sum of frame_samples
+    if (first && t == 0) {
         uint32_t r = 0;
         for (int k = 0; k < THREADS / 64; k++) r ^= s_red[k];
         const uint32_t crc = ~r;
@@ -247,7 +303,6 @@ __global__ __launch_bounds__(THREADS) void finish_files_kernel(FinishArgs A) {
         put32(p + 8, A.sample_rate);
         put8(p + 12, A.channels);
         put8(p + 13, A.bit_depth);
-        put64(p + 14, s_smp[THREADS - 1]);   // total_samples = sum of frame_samples
         put8(p + 22, A.level);
         put8(p + 23, 0); put8(p + 24, 0); put8(p + 25, 0);
         put32(p + 26, crc);
@@ -307,8 +362,16 @@ int launch_finish_files(FinishArgs A, hipStream_t s) {
     memcpy(A.byte_pow, bytep, sizeof bytep);
     memcpy(A.stripe_pow, stripep, sizeof stripep);
     hipLaunchKernelGGL(crc_slices_kernel, dim3((unsigned)A.n_clips, A.parts), dim3(kFinThreads), 0, s, A);
-    if (A.n_clips < 64) hipLaunchKernelGGL((finish_files_kernel<1024>), dim3((unsigned)A.n_clips), dim3(1024), 0, s, A);
-    else hipLaunchKernelGGL((finish_files_kernel<256>), dim3((unsigned)A.n_clips), dim3(256), 0, s, A);
+    if (A.n_clips < 64) {
+        // a few long clips: the TOC in chunks of 1024 frames (one entry per thread)
+        A.toc_chunk = 1024;
+        const unsigned chunks = A.max_frames ? (A.max_frames + 1023u) / 1024u : 1u;
+        if (!A.max_frames) A.toc_chunk = 0;
+        hipLaunchKernelGGL((finish_files_kernel<1024>), dim3((unsigned)A.n_clips, chunks), dim3(1024), 0, s, A);
+    } else {
+        A.toc_chunk = 0;
+        hipLaunchKernelGGL((finish_files_kernel<256>), dim3((unsigned)A.n_clips), dim3(256), 0, s, A);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

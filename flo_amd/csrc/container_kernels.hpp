@@ -23,6 +23,8 @@ struct FinishArgs {
     unsigned int *crc_out;                  // [n_clips] CRC32 of each DATA chunk (also in the header)
     unsigned int parts;                     // slices per clip for the CRC (1..128): few long clips still fill the chip
     unsigned int *part_reg;                 // [n_clips * parts] scratch: CRC register of every slice
+    unsigned int max_frames;                // frames of the longest clip (0 = unknown: one workgroup writes a clip's whole TOC)
+    unsigned int toc_chunk;                 // set by launch_finish_files: frames per TOC workgroup (0 = all)
     // powers of x modulo the CRC polynomial (reflected), filled in by launch_finish_files
     unsigned int x8pow2[40];                // x^(8 * 2^j)
     unsigned int blk_pow[256];              // x^(8 * 64 * i)

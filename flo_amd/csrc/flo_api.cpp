@@ -668,6 +668,8 @@ static int batch_encode_launch(flo_batch *b, int which) {
     F.crc_out = b->d_crc;
     F.parts = finish_parts_for(b->n_clips);
     F.part_reg = b->d_part;
+    F.max_frames = 0;
+    for (auto h : b->hops) F.max_frames = h > F.max_frames ? h : F.max_frames;
     return timed_launch(c, "finish_files", [&] { return launch_finish_files(F, c->stream); });
 }
 

@@ -1227,6 +1227,11 @@ int lossless_encode_launch(LosslessPlan *p, hipStream_t s, int profile, std::str
     F.crc_out = p->d_crc;
     F.parts = finish_parts_for(p->n_clips);
     F.part_reg = p->d_part;
+    F.max_frames = 0;
+    for (size_t i = 0; i < p->n_clips; i++) {
+        const unsigned nfc = (unsigned)(p->clip_first_frame[i + 1] - p->clip_first_frame[i]);
+        F.max_frames = nfc > F.max_frames ? nfc : F.max_frames;
+    }
     if (launch_finish_files(F, s) != 0) {
         err = "finish_files launch failed";
         return -1;
