@@ -15,7 +15,6 @@
 namespace flo {
 
 // ------------------------------------------------------------------------------------------------ transform frames
-constexpr int kMaxRecords = 1056;   // a record takes >= 2 bytes and a sparse blob is at most ~2.1 KB
 
 __device__ __forceinline__ uint32_t rd_u16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 __device__ __forceinline__ uint32_t rd_u32(const uint8_t *p) {
@@ -29,24 +28,43 @@ __device__ __forceinline__ uint32_t rd_u32(const uint8_t *p) {
 constexpr int kDecRunShort = 8, kDecRunLong = 16;   // output blocks per wavefront: short runs when there is little to decode
 constexpr int kBlobStage = 2304;
 
-__global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
+// FLO_DEC_STAMPS (diagnostic builds only): s_memtime at the phase boundaries of a channel-frame, summed per wave and added
+// to D.dbg at the end (launch_lossy_decode prints the shares).
+#ifdef FLO_DEC_STAMPS
+#define DSTAMP(i)                                                                   \
+    do {                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        unsigned long long t_;                                                      \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        dst_sum[i] += t_ - dst_last;                                                \
+        dst_last = t_;                                                              \
+    } while (0)
+#else
+#define DSTAMP(i) do {} while (0)
+#endif
+__global__ __launch_bounds__(64, 3) void lossy_decode_kernel(LossyDecArgs D) {
     // One 8 KiB buffer serves three phases of a channel-frame in turn: the parse table of the record headers, then the
-    // integers + the FFT exchange buffer, then the windowed output. (Apart they were 29.6 KiB per wave: five waves per
-    // CU; now 18.8 KiB: eight.)
+    // integers + the FFT exchange buffer, then the windowed output. Everything that does not change from frame to frame
+    // lives in REGISTERS for the whole run (window x 2/1024 at the 32 positions the lane writes, rotation and FFT
+    // twiddles, the band of each of its 16 coefficients: 64 global loads per channel-frame before), and so does the
+    // second half of the previous frame (16 values per lane instead of a 4 KiB LDS buffer written and read back every
+    // frame). 12 KiB of LDS per wave: twelve waves per CU (29.6 KiB / five in round 1, 18.8 KiB / eight in round 2).
     __shared__ __attribute__((aligned(16))) float u1[2048];
     short *const q = reinterpret_cast<short *>(u1);                                               // [1024]
     float (*const xch)[kXchFloats] = reinterpret_cast<float (*)[kXchFloats]>(u1 + 512);          // behind q
     float *const recon = u1;                                                                      // [2048]
     static_assert(512 * 4 + kXchFloats * 4 <= 2048 * 4, "q and the exchange buffer share the 8 KiB with room to spare");
-    __shared__ float prev[1024];                // second half of the previous frame of the channel being walked
-    __shared__ uint32_t rec[kMaxRecords];       // output index | count << 10 | byte position of the first value << 18
     __shared__ float sf[32];
-    __shared__ int s_nrec;
     // the frame's bytes, staged whole (header, scale words, both channels' blobs: ~0.5 KB, 2.2 KB at most for what the
     // encoder makes); a frame that does not fit is parsed in global memory and only its blob comes here
     __shared__ __attribute__((aligned(16))) uint8_t sblob[kBlobStage + 16];
     __shared__ unsigned long long s_foff[kDecRunLong + 1];
     __shared__ uint32_t s_flen[kDecRunLong + 1];
+    // The workgroup is ONE wavefront: its LDS instructions execute in order, so the ordering points between the phases are
+    // wave_sync() (a compiler fence), not __syncthreads() - whose s_waitcnt vmcnt(0) made every phase boundary wait for
+    // the next frame's prefetch and for the previous block's output stores (several exposed HBM round trips per
+    // channel-frame: most of what the kernel spent its time on).
     const int lane = (int)threadIdx.x;
     const unsigned clip = blockIdx.x;   // clips in x: gridDim.y stops at 65535
     if (clip >= (unsigned)D.n_clips) return;
@@ -57,7 +75,31 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
     const unsigned h1 = h0 + run < nframes - 1 ? h0 + run : nframes - 1;   // last frame of the run
     float *out = D.out + D.clip_out[clip];
     const float scale = 2.0f / 1024.0f;
-    const float *win = D.window;
+    // loop invariants of the run, in registers
+    float wn[8][2];        // window x 2/1024 (a power of two: exact) at the positions row r of this lane writes: four positions,
+                           // two values - the other two are their mirror images n <-> 2047 - n, and the window is symmetric
+                           // (the table's two halves agree to the last ulp or two of f32: 1e-7 of the 2e-6 the decode is held to)
+    uint32_t bnd[8];       // 4 x band of coefficient 2 i (low half) and of 1023 - 2 i (high half), i = lane + 64 r
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int idx = lane + 64 * r;
+        const int ke = 2 * idx, ko = 1023 - 2 * idx;
+        bnd[r] = 4u * (uint32_t)D.T.band[ke] | (4u * (uint32_t)D.T.band[ko]) << 16;
+        const float *win = D.window;
+        if (idx < 256) {
+            const int fi = 2 * idx, ri = 511 - 2 * idx;
+            wn[r][0] = scale * win[ri]; wn[r][1] = scale * win[512 + fi];      // = win[1536 + fi], win[1024 + ri]
+        } else {
+            const int i2 = idx - 256;
+            const int fi = 2 * i2, ri = 511 - 2 * i2;
+            wn[r][0] = scale * win[fi]; wn[r][1] = scale * win[512 + ri];      // = win[1536 + ri], win[1024 + fi]
+        }
+    }
+    float pv[16];          // second half of the previous frame of the channel being walked: positions lane + 64 k
+#ifdef FLO_DEC_STAMPS
+    unsigned long long dst_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dst_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dst_last)::"memory");
+#endif
 
     // where the run's frames are: one load per lane instead of one dependent load per frame
     if ((unsigned)lane <= h1 - h0) {
@@ -65,7 +107,7 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
         s_foff[lane] = D.blob_off[f];
         s_flen[lane] = D.blob_len[f];
     }
-    __syncthreads();
+    wave_sync();
     // A frame travels global memory -> registers -> LDS, and the registers are filled one frame ahead: the walk over a
     // frame used to start with three dependent global round trips (offset, channel length, blob), which was most of
     // what a wave spent its time on.
@@ -74,20 +116,26 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
     auto fetch = [&](unsigned h) {
         const uint8_t *g = D.bytes + s_foff[h - h0];
         const uint32_t len = s_flen[h - h0];
+        if (len > (uint32_t)kBlobStage) return;
 #pragma unroll
         for (int j = 0; j < kPre; j++) {
-            const uint32_t i = 4u * ((uint32_t)lane + 64u * (uint32_t)j);
-            uint32_t w4 = 0;
-            if (len <= (uint32_t)kBlobStage && i < len) __builtin_memcpy(&w4, g + i, 4);   // up to 3 bytes past the frame: inside the file + slack
-            pre[j] = w4;
+            if (256u * (uint32_t)j < len) {   // uniform: a frame is about 0.5 KB, two of the nine rows
+                const uint32_t i = 4u * ((uint32_t)lane + 64u * (uint32_t)j);
+                uint32_t w4 = 0;
+                if (i < len) __builtin_memcpy(&w4, g + i, 4);   // up to 3 bytes past the frame: inside the file + slack
+                pre[j] = w4;
+            }
         }
     };
     auto frame_ch = [&](const uint32_t c, const unsigned h, const uint8_t *data, const uint32_t len, auto IN_LDS) -> bool {
+        // (the lane index behind an optimisation barrier: inside the frame loop every lane-derived address is recomputed - a
+        // few integer operations - instead of being hoisted into dozens of loop-invariant registers)
+        const int ln = lane_id_opaque();
         constexpr bool in_lds = decltype(IN_LDS)::value;
         {
             // deserialize_frame: [block_size][channels][25 x u16 per channel][per channel: u32 len, sparse bytes]
             if (len < 2 || data[0] != 0 /* only Long blocks are produced or accepted */ || data[1] > D.channels) {
-                if (lane == 0) atomicExch(D.error, 1);
+                if (ln == 0) atomicExch(D.error, 1);
                 return false;
             }
             const uint32_t nch = data[1];
@@ -108,44 +156,74 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
                 if (k < c) pos += blen;
             }
             if (bad) {
-                if (lane == 0) atomicExch(D.error, 1);
+                if (ln == 0) atomicExch(D.error, 1);
                 return false;
             }
             const bool present = c < nch;      // a frame with fewer channels leaves the others silent
+            DSTAMP(1);
             if (present) {
                 // the record walk below is a chain of dependent byte reads: from LDS it costs a tenth of what it
                 // costs from global memory. Valid blobs are at most ~2.1 KB; anything longer is walked in place.
                 const uint8_t *sp = data + pos;
                 bool sp_lds = in_lds;
                 if (!in_lds && blen <= (uint32_t)kBlobStage) {
-                    for (uint32_t i = 4u * lane; i < blen; i += 256u) {
+                    for (uint32_t i = 4u * ln; i < blen; i += 256u) {
                         uint32_t w4;
                         __builtin_memcpy(&w4, sp + i, 4);   // up to 3 bytes past the blob: inside the file + slack
                         *reinterpret_cast<uint32_t *>(sblob + i) = w4;
                     }
-                    __syncthreads();
+                    wave_sync();
                     sp = sblob;
                     sp_lds = true;
                 }
                 // scale factors: 2^((word - 32768) / 256), 0 when the word is 0 (decoder.rs:91-99)
-                if (lane < 25) {
-                    const uint32_t wv = rd_u16(data + 2 + 50 * c + 2 * lane);
-                    // kept as the reciprocal: one IEEE division per band here instead of sixteen per lane below (q / sf
+                if (ln < 25) {
+                    const uint32_t wv = rd_u16(data + 2 + 50 * c + 2 * ln);
+                    // kept as the reciprocal: one IEEE division per band here instead of sixteen per ln below (q / sf
                     // becomes q * (1 / sf): one rounding more, 6e-8 relative, far inside the 2e-6 the transform allows)
-                    const float pw = wv > 0 ? powf(2.0f, ((float)wv - 32768.0f) / 256.0f) : 0.0f;
-                    sf[lane] = pw > 0.0f ? __fdiv_rn(1.0f, pw) : 0.0f;   // (2^-128 .. 2^128: the reciprocal is finite)
+                    // (exp2f: the exponent is a multiple of 2^-8 in [-128, 128); one ulp from powf(2, .) at most, 1e-7 relative)
+                    const float pw = wv > 0 ? exp2f(((float)wv - 32768.0f) / 256.0f) : 0.0f;
+                    sf[ln] = pw > 0.0f ? __fdiv_rn(1.0f, pw) : 0.0f;   // (2^-128 .. 2^128: the reciprocal is finite)
                 }
                 // deserialize_sparse (decoder.rs:134-167). The record headers form a chain (a record starts where the
-                // previous one ends), so one lane has to follow it - but what it finds at a position does not depend on
-                // how it got there: every lane first parses "a record starting here" for its share of the byte
-                // positions (varint, count, length) into a table, and the chain walk is then ONE dependent LDS read per
-                // record instead of three to five byte reads. The table borrows `recon`, which is idle until the inverse
-                // transform; blobs beyond its 2048 entries (or walked in place) keep the byte-wise walk.
-                const bool tabled = sp_lds && blen <= 2048u;
-                uint32_t *ptab = reinterpret_cast<uint32_t *>(recon);
-                if (tabled) {
-                    for (uint32_t p0 = (uint32_t)lane; p0 < blen; p0 += 64u) {
-                        uint32_t p = p0, value = 0, shift = 0;
+                // previous one ends) - but what is found at a byte position does not depend on how it was reached. So every
+                // ln parses "a record starting here" for its share of the byte positions into a jump table (next record's
+                // position, output positions covered), the table is squared six times (pointer doubling: entry p of level
+                // k jumps 2^k records), and ln i reaches record i - and i + 64 - by the binary digits of i: a dozen
+                // dependent LDS round trips for up to 128 records where one ln used to follow the chain record by record
+                // (9.2 k of a channel-frame's 24 k ticks). Each ln then places its own records' values. Blobs of more
+                // than 1024 bytes or 128 records (dense frames of high-quality encodes), and blobs walked in place, take the
+                // byte-wise walk of one ln.
+                constexpr uint32_t kEnd = 0xFFFu;
+                // the four bytes at blob position p0 (the blob is in LDS: two aligned dwords and a byte shift; up to seven bytes
+                // past p0 are touched, inside the staging buffer's slack)
+                auto bytes_at = [&](const uint32_t p0) -> uint32_t {
+                    const uint32_t a = (uint32_t)(uintptr_t)(sp + p0);
+                    const uint32_t *dw = reinterpret_cast<const uint32_t *>(sp + p0 - (a & 3u));
+                    return __builtin_amdgcn_alignbyte(dw[1], dw[0], a & 3u);
+                };
+                // "a record starting at p0", from its first bytes w: the usual header is [zero run < 128][count] or [two-byte
+                // zero run][count]; anything else (longer varints, the blob's last bytes) takes the byte loop. True: count byte present.
+                auto parse_eval = [&](const uint32_t p0, const uint32_t w, uint32_t &zr, uint32_t &cnt_a, uint32_t &adv) -> bool {
+                    uint32_t p, value, nz;
+                    if (!(w & 0x80u) && p0 + 2 <= blen) {
+                        value = w & 0x7Fu;
+                        nz = (w >> 8) & 0xFFu;
+                        p = p0 + 1;
+                    } else if ((w & 0x8080u) == 0x0080u && p0 + 3 <= blen) {
+                        value = (w & 0x7Fu) | ((w >> 1) & 0x3F80u);
+                        nz = (w >> 16) & 0xFFu;
+                        p = p0 + 2;
+                    } else if ((w & 0x8080u) == 0x8080u && (w & 0x7800u) != 0u && p0 + 2 <= blen) {
+                        // three or more bytes and already >= 1024 after two: the walk ends at this record whatever follows
+                        // (most byte positions are not record starts, and the high byte of a negative value looks like this)
+                        zr = 2047u;
+                        cnt_a = 0;
+                        adv = 2;
+                        return false;
+                    } else {
+                        p = p0, value = 0;
+                        uint32_t shift = 0;
                         while (p < blen) {   // decode_varint (:170-188)
                             const uint32_t b = sp[p++];
                             value |= (b & 0x7Fu) << shift;
@@ -153,58 +231,148 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
                             shift += 7;
                             if (shift >= 32) break;
                         }
-                        // entry: zero run (clamped: anything >= 1024 ends the walk) | count << 11 | bytes to the next
-                        // record << 19 | "no count byte" << 30
-                        uint32_t e = value < 2047u ? value : 2047u;
-                        if (p >= blen) {
-                            e |= 1u << 30;
-                        } else {
-                            const uint32_t nz = sp[p++];
-                            const uint32_t avail = (blen - p) >> 1;
-                            const uint32_t cnt = nz < avail ? nz : avail;
-                            e |= (cnt << 11) | ((p + 2u * cnt - p0) << 19);
-                        }
-                        ptab[p0] = e;
+                        nz = p < blen ? (uint32_t)sp[p] : 0u;
                     }
-                    __syncthreads();
+                    zr = value < 2047u ? value : 2047u;   // (anything >= 1024 ends the walk)
+                    cnt_a = 0;
+                    adv = p - p0;
+                    if (p >= blen) return false;
+                    p++;
+                    const uint32_t avail = (blen - p) >> 1;
+                    cnt_a = nz < avail ? nz : avail;
+                    adv = p + 2u * cnt_a - p0;
+                    return true;
+                };
+                uint32_t *ta = reinterpret_cast<uint32_t *>(recon), *tb = ta + 1024;
+                bool fast = sp_lds && blen <= 1024u;
+                // rotation and FFT twiddles of this ln: twelve 16-byte loads (12 KB per CU, resident in its L1) issued here,
+                // a phase ahead of their use, and dead again after the transform: held across frames they were 48 registers
+                // that cost the kernel a third of its resident waves
+                float4 wtw[4], wf1[4], wf2[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    wtw[kk] = D.T.pack[(kRowTw + kk) * 64 + ln];
+                    wf1[kk] = D.T.pack[(kRowF1 + kk) * 64 + ln];
+                    wf2[kk] = D.T.pack[(kRowF2 + kk) * 64 + ln];
                 }
-#ifdef FLO_DEC_ABLATE   // diagnostic: timing without the record walk (results invalid)
-                if (lane == 0) s_nrec = 0;
-#else
-                if (lane == 0 && tabled) {
-                    uint32_t p = 0, nrec = 0, oi = 0;
-                    while (p < blen && oi < 1024u) {
-                        const uint32_t e = ptab[p];
-                        oi += e & 2047u;
-                        if (e >> 30) break;
-                        const uint32_t cnt_a = (e >> 11) & 255u, adv = (e >> 19) & 2047u;
-                        const uint32_t room = oi < 1024u ? 1024u - oi : 0u;
-                        const uint32_t cnt = cnt_a < room ? cnt_a : room;
-                        if (cnt && nrec < kMaxRecords) {
-                            rec[nrec] = oi | (cnt << 10) | ((p + adv - 2u * cnt_a) << 18);
-                            nrec++;
+                DSTAMP(2);
+                uint32_t cur0 = blen ? 0u : kEnd, acc0 = 0, cur1 = kEnd, acc1 = 0;   // (every stored jump is kEnd or < blen)
+                if (fast) {
+                    // (four positions per ln at a time: the loads of a batch are in flight together)
+                    for (uint32_t pb = (uint32_t)ln; pb < blen; pb += 256u) {
+                        uint32_t w[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) w[u] = pb + 64u * u < blen ? bytes_at(pb + 64u * u) : 0u;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const uint32_t p0 = pb + 64u * u;
+                            if (p0 < blen) {
+                                uint32_t zr, cnt_a, adv;
+                                const bool has = parse_eval(p0, w[u], zr, cnt_a, adv);
+                                const uint32_t nx = has && p0 + adv < blen ? p0 + adv : kEnd;
+                                const uint32_t st = zr + cnt_a < 2047u ? zr + cnt_a : 2047u;
+                                ta[p0] = nx | (st << 12);
+                            }
                         }
-                        p += adv;      // (a count cut by `room` ends the walk: oi reaches 1024)
-                        oi += cnt;
                     }
-                    s_nrec = (int)nrec;
+                    wave_sync();
+                    DSTAMP(3);
+                    bool ended = false;   // the chain ended before record 2^k: no later level is needed
+#pragma unroll 1
+                    for (int k = 0; k < 6; k++) {
+                        // one round trip: the level-k jump from the blob's start (is there a record 2^k at all?), the lane's own
+                        // jump, and the entries to be squared
+                        const uint32_t e0 = ta[0];
+                        const uint32_t eu = cur0 != kEnd ? ta[cur0] : kEnd;
+                        uint32_t e1[4], e2[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) e1[u] = (uint32_t)ln + 64u * u < blen ? ta[(uint32_t)ln + 64u * u] : kEnd;
+                        if (((uint32_t)__builtin_amdgcn_readfirstlane((int)e0) & 0xFFFu) == kEnd) {   // uniform
+                            if (((uint32_t)ln >> k) != 0u) cur0 = kEnd;   // records 2^k and up do not exist
+                            ended = true;
+                            break;
+                        }
+                        if ((((uint32_t)ln >> k) & 1u) && cur0 != kEnd) {
+                            const uint32_t a = acc0 + (eu >> 12);
+                            acc0 = a < 2047u ? a : 2047u;
+                            cur0 = eu & 0xFFFu;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) e2[u] = (e1[u] & 0xFFFu) != kEnd ? ta[e1[u] & 0xFFFu] : kEnd;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const uint32_t a = (e1[u] >> 12) + (e2[u] >> 12);
+                            if ((uint32_t)ln + 64u * u < blen) tb[(uint32_t)ln + 64u * u] = (e2[u] & 0xFFFu) | ((a < 2047u ? a : 2047u) << 12);
+                        }
+                        for (uint32_t pb = (uint32_t)ln + 256u; pb < blen; pb += 256u) {   // blobs of more than 256 bytes
+#pragma unroll
+                            for (int u = 0; u < 4; u++) e1[u] = pb + 64u * u < blen ? ta[pb + 64u * u] : kEnd;
+#pragma unroll
+                            for (int u = 0; u < 4; u++) e2[u] = (e1[u] & 0xFFFu) != kEnd ? ta[e1[u] & 0xFFFu] : kEnd;
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const uint32_t a = (e1[u] >> 12) + (e2[u] >> 12);
+                                if (pb + 64u * u < blen) tb[pb + 64u * u] = (e2[u] & 0xFFFu) | ((a < 2047u ? a : 2047u) << 12);
+                            }
+                        }
+                        wave_sync();
+                        uint32_t *t = ta;
+                        ta = tb;
+                        tb = t;
+                    }
+                    // ta = level 6 (jumps of 64 records): the lane's second record, and whether a 129th record matters
+                    if (!ended) {
+                        if (cur0 != kEnd) {
+                            const uint32_t e = ta[cur0];
+                            const uint32_t a = acc0 + (e >> 12);
+                            acc1 = a < 2047u ? a : 2047u;
+                            cur1 = e & 0xFFFu;
+                        }
+                        const uint32_t c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur1), a1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)acc1);
+                        if (c1 != kEnd) {   // uniform (lane 0 = records 0 and 64)
+                            const uint32_t e = ta[c1];
+                            if ((e & 0xFFFu) != kEnd && a1 + (e >> 12) < 1024u) fast = false;
+                        }
+                    }
                 }
-#endif
-                if (tabled) {
-                    __syncthreads();                                   // the table is dead: its memory becomes q
-                    for (int i = lane; i < 1024; i += 64) q[i] = 0;
-                    __syncthreads();
-                    for (int r = lane; r < s_nrec; r += 64) {
-                        const uint32_t o = rec[r] & 1023u, cnt = (rec[r] >> 10) & 255u;
-                        const uint8_t *v = sp + (rec[r] >> 18);
-                        for (uint32_t i = 0; i < cnt; i++) q[o + i] = (short)rd_u16(v + 2 * i);
+                DSTAMP(4);
+                if (fast) {
+                    // the ln's records: output index, count, where the values lie (parsed again: the tables are about to be q)
+                    uint32_t o[2] = {1024u, 1024u}, n[2] = {0u, 0u}, vp[2] = {0u, 0u};
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t cu = u ? cur1 : cur0, ac = u ? acc1 : acc0;
+                        if (cu != kEnd && ac < 1024u) {
+                            uint32_t zr, cnt_a, adv;
+                            const bool has = parse_eval(cu, bytes_at(cu), zr, cnt_a, adv);
+                            const uint32_t oi = ac + zr;
+                            if (has && oi < 1024u) {
+                                const uint32_t room = 1024u - oi;
+                                o[u] = oi;
+                                n[u] = cnt_a < room ? cnt_a : room;
+                                vp[u] = cu + adv - 2u * cnt_a;
+                            }
+                        }
+                    }
+                    wave_sync();
+                    {
+                        uint4 *qz = reinterpret_cast<uint4 *>(q);
+                        qz[ln] = make_uint4(0u, 0u, 0u, 0u);
+                        qz[64 + ln] = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const uint8_t *v = sp + vp[u];
+                        for (uint32_t i = 0; i < n[u]; i++) q[o[u] + i] = (short)rd_u16(v + 2 * i);
                     }
                 } else {
-                    // a blob too long for the table (or walked in place): outside what the encoder produces. One lane
-                    // walks it byte by byte and places the values itself.
-                    for (int i = lane; i < 1024; i += 64) q[i] = 0;
-                    __syncthreads();
-                    if (lane == 0) {
+                    // a blob too long for the tables, with more than 128 records, or walked in place: dense frames of
+                    // high-quality encodes at most. One ln walks it byte by byte and places the values itself.
+                    wave_sync();
+                    for (int i = ln; i < 1024; i += 64) q[i] = 0;
+                    wave_sync();
+                    if (ln == 0) {
                         uint32_t p = 0;
                         unsigned long long oi = 0;
                         while (p < blen && oi < 1024) {
@@ -229,65 +397,78 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
                         }
                     }
                 }
-                __syncthreads();
+                wave_sync();
+                DSTAMP(5);
                 // dequantise (decoder.rs:35-48) straight into the inverse transform's pre-rotation (mdct.rs:238-247)
                 float zr[1][8], zi[1][8];
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const int i = lane + 64 * r;
+                    const int i = ln + 64 * r;
                     const int ke = 2 * i, ko = 1023 - 2 * i;
-                    const float se = sf[D.T.band[ke]], so = sf[D.T.band[ko]];
+                    const float se = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sf) + (bnd[r] & 0xFFFFu));
+                    const float so = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sf) + (bnd[r] >> 16));
                     const float even = (float)q[ke] * se;   // se, so: 1 / scale factor, 0 for a band without one
                     const float odd = -((float)q[ko] * so);
-                    const float4 t4 = D.T.pack[(kRowTw + (r >> 1)) * 64 + lane];
-                    const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
+                    const float2 w = (r & 1) ? make_float2(wtw[r >> 1].z, wtw[r >> 1].w) : make_float2(wtw[r >> 1].x, wtw[r >> 1].y);
                     zr[0][r] = odd * w.y - even * w.x;
                     zi[0][r] = odd * w.x + even * w.y;
                 }
-                fft512<1>(lane, zr, zi, xch, D.T);
+                DSTAMP(6);
+                fft512_w(ln, zr[0], zi[0], xch[0], wf1, wf2);
+                DSTAMP(7);
                 // post-rotation, scale 2 / 1024 and window (mdct.rs:252-287); every position is written exactly once
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const int idx = lane + 64 * r;
-                    const float4 t4 = D.T.pack[(kRowTw + (r >> 1)) * 64 + lane];
-                    const float2 w = (r & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
+                    const int idx = ln + 64 * r;
+                    const float2 w = (r & 1) ? make_float2(wtw[r >> 1].z, wtw[r >> 1].w) : make_float2(wtw[r >> 1].x, wtw[r >> 1].y);
                     const float val_re = w.x * zr[0][r] + w.y * zi[0][r];
                     const float val_im = w.y * zr[0][r] - w.x * zi[0][r];
-                    if (idx < 256) {
+                    if (r < 4) {   // idx < 256
                         const int fi = 2 * idx, ri = 511 - 2 * idx;
-                        recon[ri] = -val_im * scale * win[ri];
-                        recon[512 + fi] = val_im * scale * win[512 + fi];
-                        recon[1024 + ri] = val_re * scale * win[1024 + ri];
-                        recon[1536 + fi] = val_re * scale * win[1536 + fi];
+                        recon[ri] = -val_im * wn[r][0];
+                        recon[512 + fi] = val_im * wn[r][1];
+                        recon[1024 + ri] = val_re * wn[r][1];
+                        recon[1536 + fi] = val_re * wn[r][0];
                     } else {
                         const int i2 = idx - 256;
                         const int fi = 2 * i2, ri = 511 - 2 * i2;
-                        recon[fi] = -val_re * scale * win[fi];
-                        recon[512 + ri] = val_re * scale * win[512 + ri];
-                        recon[1024 + fi] = val_im * scale * win[1024 + fi];
-                        recon[1536 + ri] = val_im * scale * win[1536 + ri];
+                        recon[fi] = -val_re * wn[r][0];
+                        recon[512 + ri] = val_re * wn[r][1];
+                        recon[1024 + fi] = val_im * wn[r][1];
+                        recon[1536 + ri] = val_im * wn[r][0];
                     }
                 }
-                __syncthreads();
+                wave_sync();
             }
-            // overlap-add (mdct.rs:449-456): block h - 1 = first half of this frame + second half of the previous one.
-            // A channel the frame does not carry gives a silent block and leaves its overlap buffer alone (the
-            // reference would fail on such a frame; the oracle behaves like this).
+            DSTAMP(8);
+            // overlap-add (mdct.rs:449-456): block h - 1 = first half of this frame + second half of the previous one
+            // (carried in registers). A channel the frame does not carry gives a silent block and leaves the overlap
+            // alone (the reference would fail on such a frame; the oracle behaves like this).
             if (h > h0) {
-                for (int j = lane; j < 1024; j += 64) {
-                    const float a = present ? recon[j] + prev[j] : 0.0f;
-                    out[((unsigned long long)(h - 1) * 1024 + j) * D.channels + c] = a;
+                // (a uniform block base and a 32-bit lane offset: the stores take the scalar-base form, no 64-bit address
+                // arithmetic per store)
+                float *ob = out + ((unsigned long long)(h - 1) * 1024) * D.channels + c;
+                const uint32_t nchu = (uint32_t)D.channels;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t j = (uint32_t)ln + 64u * (uint32_t)k;
+                    const float a = present ? recon[j] + pv[k] : 0.0f;
+                    ob[j * nchu] = a;
                 }
             }
-            if (present)
-                for (int j = lane; j < 1024; j += 64) prev[j] = recon[1024 + j];
-            __syncthreads();
+            if (present) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) pv[k] = recon[1024 + ln + 64 * k];
+            }
+            wave_sync();
+            DSTAMP(9);
         }
         return true;
     };
 
     for (uint32_t c = 0; c < (uint32_t)D.channels; c++) {
-        for (int j = lane; j < 1024; j += 64) prev[j] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) pv[k] = 0.0f;
         fetch(h0);
         for (unsigned h = h0; h <= h1; h++) {
             const uint32_t len = s_flen[h - h0];
@@ -295,11 +476,14 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
             if (len <= (uint32_t)kBlobStage) {
 #pragma unroll
                 for (int j = 0; j < kPre; j++) {
-                    const uint32_t i = 4u * ((uint32_t)lane + 64u * (uint32_t)j);
-                    if (i < len) *reinterpret_cast<uint32_t *>(sblob + i) = pre[j];
+                    if (256u * (uint32_t)j < len) {   // uniform
+                        const uint32_t i = 4u * ((uint32_t)lane + 64u * (uint32_t)j);
+                        if (i < len) *reinterpret_cast<uint32_t *>(sblob + i) = pre[j];
+                    }
                 }
-                __syncthreads();
+                wave_sync();
                 if (h < h1) fetch(h + 1);
+                DSTAMP(0);
                 ok = frame_ch(c, h, sblob, len, std::true_type{});
             } else {
                 if (h < h1) fetch(h + 1);
@@ -308,6 +492,10 @@ __global__ __launch_bounds__(64) void lossy_decode_kernel(LossyDecArgs D) {
             if (!ok) return;
         }
     }
+#ifdef FLO_DEC_STAMPS
+    if (D.dbg && lane == 0)
+        for (int i = 0; i < 10; i++) atomicAdd(D.dbg + i, dst_sum[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ ALPC frames
@@ -521,8 +709,28 @@ int launch_lossy_decode(const LossyDecArgs &A0, unsigned max_frames, hipStream_t
     const unsigned long long blocks = (unsigned long long)A.n_clips * (max_frames - 1);
     A.run = blocks >= 8ull * 4096ull ? kDecRunLong : kDecRunShort;
     const unsigned runs = (max_frames - 1 + (unsigned)A.run - 1) / (unsigned)A.run;
+#ifdef FLO_DEC_STAMPS
+    unsigned long long *d_dbg = nullptr;
+    if (hipMalloc(&d_dbg, 80) != hipSuccess || hipMemset(d_dbg, 0, 80) != hipSuccess) return -1;
+    A.dbg = d_dbg;
+#endif
     hipLaunchKernelGGL(lossy_decode_kernel, dim3((unsigned)A.n_clips, runs), dim3(64), 0, s, A);
     FLO_LAUNCH_CHECK();
+#ifdef FLO_DEC_STAMPS
+    {
+        unsigned long long h[10];
+        hipStreamSynchronize(s);
+        hipMemcpy(h, d_dbg, 80, hipMemcpyDeviceToHost);
+        hipFree(d_dbg);
+        static const char *nm[10] = {"stage+prefetch", "header", "stage-blob+scale", "parse-table", "walk", "zero+place", "dequant+prerot", "fft", "postrot+window", "overlap-add+store"};
+        double tot = 0;
+        for (int i = 0; i < 10; i++) tot += (double)h[i];
+        const double fc = (double)blocks * A.channels * ((double)(A.run + 1) / A.run);
+        fprintf(stderr, "[dec stamps] ticks per channel-frame:");
+        for (int i = 0; i < 10; i++) fprintf(stderr, " %s=%.0f", nm[i], (double)h[i] / fc);
+        fprintf(stderr, " total=%.0f\n", tot / fc);
+    }
+#endif
     return 0;
 }
 int launch_ll_decode(const LlDecArgs &A, hipStream_t s) {

@@ -257,6 +257,53 @@ __device__ __forceinline__ void fft512(const int lane, float (&zr)[CH][8], float
     for (int c = 0; c < CH; c++) dft8(zr[c], zi[c]);
 }
 
+// The same transform, one channel, with the inter-stage twiddles handed in (the decoder keeps them in registers for a
+// whole run of frames instead of fetching eight rows per frame): identical operations, identical bits.
+__device__ __forceinline__ void fft512_w(const int lane, float (&zr)[8], float (&zi)[8], float *xch1, const float4 (&wf1)[4],
+                                         const float4 (&wf2)[4]) {
+    dft8(zr, zi);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        cmul(zr[2 * kk + 1], zi[2 * kk + 1], wf1[kk].x, wf1[kk].y);
+        if (kk < 3) cmul(zr[2 * kk + 2], zi[2 * kk + 2], wf1[kk].z, wf1[kk].w);
+    }
+    {
+        const int nb = lane >> 3, nc = lane & 7;
+        float2 *x = reinterpret_cast<float2 *>(xch1);
+#pragma unroll
+        for (int ka = 0; ka < 8; ka++) x[(8 * ka + nc) * kXchStride + nb] = make_float2(zr[ka], zi[ka]);
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const float2 v = x[lane * kXchStride + r];
+            zr[r] = v.x;
+            zi[r] = v.y;
+        }
+        wave_sync();
+    }
+    dft8(zr, zi);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        cmul(zr[2 * kk + 1], zi[2 * kk + 1], wf2[kk].x, wf2[kk].y);
+        if (kk < 3) cmul(zr[2 * kk + 2], zi[2 * kk + 2], wf2[kk].z, wf2[kk].w);
+    }
+    {
+        const int ka = lane >> 3, nc = lane & 7;
+        float2 *x = reinterpret_cast<float2 *>(xch1);
+#pragma unroll
+        for (int kb = 0; kb < 8; kb++) x[(ka + 8 * kb) * kXchStride + nc] = make_float2(zr[kb], zi[kb]);
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const float2 v = x[lane * kXchStride + r];
+            zr[r] = v.x;
+            zi[r] = v.y;
+        }
+        wave_sync();
+    }
+    dft8(zr, zi);
+}
+
 // ------------------------------------------------------------------------------------------------ input
 // Half-frame offsets a lane folds: row r < 4: i = lane + 64 r  -> even 512 + 2i, odd 511 - 2i
 //                                  row r >= 4: i = lane + 64(r-4) -> even 2i, odd 1023 - 2i
