@@ -995,7 +995,11 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
             am.z = max_abs_raw(am.z, c[e].x);
             am.w = max_abs_raw(am.w, c[e].y);
             if ((dirty >> e) & 1u) {   // compile-time
+#ifdef FLO_MASKED_SLOTS   // diagnostic: only the lanes that close a segment here store (the others' stores went to per-lane trash slots)
+                if (kp[k] == 0.0f || e == 15) *reinterpret_cast<lds_v4f *>((uintptr_t)(s0 + 2u * dv[k])) = am;
+#else
                 *reinterpret_cast<lds_v4f *>((uintptr_t)(s0 + 2u * dv[k])) = am;
+#endif
                 if (e < 15) {
                     am.xy = am.xy * splat2(kp[k]);
                     am.zw = am.zw * splat2(kp[k]);

@@ -29,6 +29,9 @@
 #endif
 // FLO_ABLATE3=n (three-wave form): 1 packer does nothing | 2 + channel waves stop after the transform |
 //   3 + no post-rotation/transposition | 4 + no FFT (loads and fold only)
+#ifndef FLO_SKIP
+#define FLO_SKIP 0
+#endif
 #ifndef FLO_ABLATE3
 #define FLO_ABLATE3 0
 #endif
@@ -985,10 +988,17 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             load_half_fast_2(ln, pcm, (long long)(h + 1) * 1024, pe, po);
             FLO_MARK("prefetch_done");
             STAMP(1);
+#if (FLO_SKIP & 8) == 0   // FLO_SKIP (diagnostic builds, results invalid): leave a phase out to see what it costs in a counter
             fft512_2(ln, zr, zi, lds.u.xch4, T);
+#endif
             FLO_MARK("fft_done");
             STAMP(2);
+#if (FLO_SKIP & 4) == 0
             post_rotate_transpose_2(ln, zr, zi, lds.u.coef2, c, T);
+#else
+#pragma unroll
+            for (int e = 0; e < 8; e++) { c[2 * e] = zr[e]; c[2 * e + 1] = zi[e]; }
+#endif
             FLO_MARK("postrot_done");
             STAMP(3);
 
@@ -1003,7 +1013,12 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         }
         // band statistics, masking level, temporal masking, scale factors (analyse_frame, both channels)
         float energy1, bmax1;   // channel 0's band b on lane b, channel 1's on lane 32 + b
+#if (FLO_SKIP & 1) == 0
         band_stats_2<DIRTY>(ln, c, lds, T, energy1, bmax1);
+#else
+        energy1 = c[0].x + c[5].y;
+        bmax1 = c[1].x + c[7].y;
+#endif
         FLO_MARK("bandstats_done");
         STAMP(4);
         QuantRows qrows;   // in flight under the masking pass
@@ -1032,7 +1047,12 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         FLO_MARK("mask_done");
         STAMP(5);
         uint32_t xs[2][8];
+#if (FLO_SKIP & 2) == 0
         quantise_2(ln, c, lds, T, qrows, xs);
+#else
+#pragma unroll
+        for (int k = 0; k < 8; k++) { xs[0][k] = __float_as_uint(c[2 * k].x) & 0x00010001u; xs[1][k] = __float_as_uint(c[2 * k + 1].y) & 0x00010001u; }
+#endif
         FLO_MARK("quant_done");
         STAMP(6);
         if (DBG && A.dbg_q) {
