@@ -47,6 +47,8 @@ class Stager {
         bool in_use = false;
     };
     std::vector<PinBlock> blocks;   // pinned download buffers, kept for the next call
+    hipStream_t aux_stream = nullptr;   // the second uploading thread's stream and its "done" event
+    hipEvent_t aux_ev = nullptr, aux_go = nullptr;
 
     void worker() {
         std::unique_lock<std::mutex> lk(mu);
@@ -125,6 +127,9 @@ void stager_destroy(Stager *s) {
     }
     if (s->pinned) hipHostFree(s->pinned);
     for (auto &b : s->blocks) hipHostFree(b.p);
+    if (s->aux_ev) hipEventDestroy(s->aux_ev);
+    if (s->aux_go) hipEventDestroy(s->aux_go);
+    if (s->aux_stream) hipStreamDestroy(s->aux_stream);
     delete s;
 }
 
@@ -180,11 +185,53 @@ int stager_upload(Stager *s, const std::vector<UploadSeg> &segs, hipStream_t str
         return e ? (size_t)atoi(e) << 20 : kSmallUpload;
     }();
     if (total <= small_limit) {
-        for (const UploadSeg &g : segs)
-            if (g.bytes && hipMemcpyAsync(g.dst, g.src, g.bytes, hipMemcpyHostToDevice, stream) != hipSuccess) {
-                err = "hipMemcpyAsync (upload) failed";
+        // Several clips: a second thread issues half of the copies on a stream of its own (FLO_UPLOAD_THREADS=1 turns it off).
+        // One pageable copy keeps one staging pipeline of the runtime busy; two in flight come closer to the PCIe rate.
+        static const bool two = [] {
+            const char *e = getenv("FLO_UPLOAD_THREADS");
+            return !e || atoi(e) >= 2;
+        }();
+        size_t split = segs.size();
+        if (two && segs.size() >= 2 && total >= ((size_t)16 << 20)) {
+            size_t acc = 0;
+            for (split = 0; split < segs.size() && acc < total / 2; split++) acc += segs[split].bytes;
+            if (!s->aux_stream && (hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+                                   hipEventCreateWithFlags(&s->aux_ev, hipEventDisableTiming) != hipSuccess ||
+                                   hipEventCreateWithFlags(&s->aux_go, hipEventDisableTiming) != hipSuccess))
+                split = segs.size();
+            // the second stream's copies land behind whatever `stream` has been ordered behind (the batch's zero fill)
+            if (split < segs.size() && (hipEventRecord(s->aux_go, stream) != hipSuccess || hipStreamWaitEvent(s->aux_stream, s->aux_go, 0) != hipSuccess))
+                split = segs.size();
+        }
+        int dev = 0;
+        bool aux_ok = true;
+        std::thread helper;
+        if (split < segs.size()) {
+            if (hipGetDevice(&dev) != hipSuccess) {
+                err = "hipGetDevice failed";
                 return -1;
             }
+            helper = std::thread([&, dev] {
+                if (hipSetDevice(dev) != hipSuccess) {
+                    aux_ok = false;
+                    return;
+                }
+                for (size_t i = split; i < segs.size(); i++)
+                    if (segs[i].bytes && hipMemcpyAsync(segs[i].dst, segs[i].src, segs[i].bytes, hipMemcpyHostToDevice, s->aux_stream) != hipSuccess) aux_ok = false;
+                if (hipEventRecord(s->aux_ev, s->aux_stream) != hipSuccess) aux_ok = false;
+            });
+        }
+        bool ok = true;
+        for (size_t i = 0; i < split; i++)
+            if (segs[i].bytes && hipMemcpyAsync(segs[i].dst, segs[i].src, segs[i].bytes, hipMemcpyHostToDevice, stream) != hipSuccess) ok = false;
+        if (helper.joinable()) {
+            helper.join();
+            if (!aux_ok || hipStreamWaitEvent(stream, s->aux_ev, 0) != hipSuccess) ok = false;
+        }
+        if (!ok) {
+            err = "hipMemcpyAsync (upload) failed";
+            return -1;
+        }
         return 0;
     }
     if (!ensure_ring(s, err)) return -1;

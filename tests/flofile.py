@@ -174,3 +174,38 @@ def build_lossless(sample_rate: int, channels: int, frames, version=(1, 2), bit_
     head += struct.pack("<IQQQQQ", zlib.crc32(bytes(data)) & 0xFFFFFFFF, 66, len(tocb), len(data), 0, 0)
     assert len(head) == 70
     return head + tocb + bytes(data)
+
+
+def build_transform(sample_rate: int, channels: int, frames, quality_byte=140) -> bytes:
+    """Writer for hand-made transform (lossy) files (tests only). `frames` = [[(sf_words[25], sparse_bytes), ... per
+    channel], ...]; every frame is a Long block of 1024 sample-frames (writer.rs:236-254, encoder.rs:243-280)."""
+    data = bytearray()
+    toc = []
+    for i, chans in enumerate(frames):
+        blob = bytes([0, len(chans)])
+        for sfw, _ in chans:
+            blob += struct.pack("<25H", *[int(x) for x in sfw])
+        for _, sp in chans:
+            blob += struct.pack("<I", len(sp)) + bytes(sp)
+        off = len(data)
+        data += struct.pack("<BIB", 253, 1024, 0) + struct.pack("<I", len(blob)) + blob
+        toc.append((i, off, len(data) - off, i * 1024 * 1000 // max(sample_rate, 1)))
+    tocb = struct.pack("<I", len(toc)) + b"".join(struct.pack("<IQII", *t) for t in toc)
+    total = 1024 * len(frames)
+    flags = 0x01 | (quality_byte << 8)
+    head = b"FLO!" + struct.pack("<BBHIBBQB", 1, 2, flags, sample_rate, channels, 16, total, 5) + b"\0\0\0"
+    head += struct.pack("<IQQQQQ", zlib.crc32(bytes(data)) & 0xFFFFFFFF, 66, len(tocb), len(data), 0, 0)
+    assert len(head) == 70
+    return head + tocb + bytes(data)
+
+
+def encode_varint(v: int) -> bytes:
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)

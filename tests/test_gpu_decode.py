@@ -135,6 +135,72 @@ def test_long_zero_runs_and_dense_frames_decode(ctx):
         assert g.shape == o.shape and np.max(np.abs(g - o), initial=0.0) <= LOSSY_TOL * max(1.0, float(np.max(np.abs(o), initial=0.0)))
 
 
+def _sparse_blob(records):
+    """[(zero_run, [values...]) ...] -> sparse bytes (encoder.rs:284-314 layout: varint zeros, count, i16 values)"""
+    out = bytearray()
+    for z, vals in records:
+        out += flofile.encode_varint(z) + bytes([len(vals)]) + np.asarray(vals, dtype="<i2").tobytes()
+    return bytes(out)
+
+
+@pytest.mark.parametrize("n_rec", [0, 1, 2, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, 340])
+def test_hand_made_record_chains_decode_like_the_oracle(ctx, n_rec):
+    # the device resolves the record chain by pointer doubling: lane i reaches records i and i + 64, more than 128 records
+    # or 1024 bytes take the one-lane walk. Chains of every length around those borders, one- and two-byte zero runs,
+    # a record that overruns position 1023 and is cut, records behind it that must be ignored.
+    rng = np.random.default_rng(100 + n_rec)
+    sfw = [32768 + 256 * 3] * 25    # scale factor 2^3: a few thousand in a coefficient decodes to about 1.0
+    frames = []
+    for f in range(3):
+        chans = []
+        for c in range(2):
+            recs, pos = [], 0
+            for r in range(n_rec):
+                z = int(rng.integers(0, 4)) if r % 7 else int(rng.integers(0, 2)) * 130   # now and then a two-byte zero run
+                cnt = int(rng.integers(1, 3))
+                if n_rec <= 129 and pos + z + cnt > 1024 - 2 * (n_rec - r):   # keep short chains inside the frame
+                    z = 0
+                    cnt = 1
+                recs.append((z, [int(v) for v in rng.integers(-3000, 3000, cnt)]))
+                pos += z + cnt
+            chans.append((sfw, _sparse_blob(recs)))
+        frames.append(chans)
+    flo = flofile.build_transform(44100, 2, frames)
+    want = O.decode(flo)[0]
+    got = ctx.decode(flo)
+    assert got.shape == want.shape and want.size == 2 * 2048
+    assert np.max(np.abs(got - want)) <= LOSSY_TOL * max(1.0, float(np.max(np.abs(want))))
+    if n_rec:
+        assert float(np.max(np.abs(want))) > 0
+
+
+def test_hand_made_odd_record_headers_decode_like_the_oracle(ctx):
+    # non-canonical and oversized varints, counts that run past the blob, a blob that ends inside a header, 255-long records,
+    # blobs just under and over 1024 bytes: whatever the oracle decoder makes of them, the device makes too
+    sfw = [32768 + 256 * 3] * 25
+    v = lambda n, s=1: [((7 * i * s) % 4001) - 2000 for i in range(n)]
+    blobs = [
+        b"\x85\x80\x00" + bytes([2]) + np.asarray([5, -5], "<i2").tobytes(),            # 5 as a three-byte varint
+        b"\x80\x80\x80\x80\x00" + bytes([1]) + np.asarray([9], "<i2").tobytes(),      # 0 as a five-byte varint
+        b"\xff\xff\xff\xff\x7f" + bytes([1]) + np.asarray([9], "<i2").tobytes(),      # a huge zero run: nothing decodes
+        _sparse_blob([(3, v(2))]) + b"\x02\x09" + b"\x11",                              # count 9, one byte of values left
+        _sparse_blob([(3, v(2))]) + b"\x81",                                             # ends inside a varint
+        _sparse_blob([(0, v(255)), (1, v(255, 3)), (2, v(255, 5)), (0, v(200, 7))]),      # 255-capped records, ~1.9 KB
+        _sparse_blob([(0, v(250)), (2, v(250, 3))]) + _sparse_blob([(1, v(1))] * 4),      # 1018 bytes
+        _sparse_blob([(0, v(250)), (2, v(250, 3))]) + _sparse_blob([(1, v(1))] * 6),      # 1026 bytes
+        _sparse_blob([(1000, v(30))]),                                                    # cut at position 1023
+        _sparse_blob([(1020, v(2)), (1, v(3)), (0, v(5)), (4, v(1))]),                    # the third record is cut, the fourth ignored
+        b"",
+    ]
+    for i, blob in enumerate(blobs):
+        frames = [[(sfw, blob), (sfw, blobs[(i + 3) % len(blobs)])] for _ in range(3)]
+        flo = flofile.build_transform(48000, 2, frames)
+        want = O.decode(flo)[0]
+        got = ctx.decode(flo)
+        assert got.shape == want.shape, i
+        assert np.max(np.abs(got - want), initial=0.0) <= LOSSY_TOL * max(1.0, float(np.max(np.abs(want), initial=0.0))), i
+
+
 def test_empty_and_tiny_files(ctx):
     for n in (0, 1, 1024, 1025):
         pcm = signals.fast_noise(n * 2, 4, 0.3)

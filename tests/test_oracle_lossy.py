@@ -154,3 +154,22 @@ def test_lossy_edge_inputs():
     x = signals.fast_noise(4096, 2)
     x[100], x[200], x[300] = np.nan, np.inf, -np.inf
     assert flofile.parse(O.encode_lossy(x, 44100, 2, 0.55)).crc_valid
+
+
+def test_hand_made_transform_files_parse_and_decode():
+    """tests/flofile.build_transform (the writer of the GPU decode tests' hand-made record chains) makes files the
+    independent parser and the oracle decoder both accept, with the coefficients that were put in."""
+    import flofile
+    sfw = [32768 + 256 * 3] * 25
+    vals = np.array([100, -200, 300], dtype="<i2")
+    blob = flofile.encode_varint(5) + bytes([3]) + vals.tobytes() + flofile.encode_varint(200) + bytes([1]) + np.array([7], "<i2").tobytes()
+    flo = flofile.build_transform(44100, 2, [[(sfw, blob), (sfw, b"")]] * 3)
+    f = flofile.parse(flo)
+    assert f.crc_valid and f.is_lossy and len(f.frames) == 3 and f.total_samples == 3 * 1024
+    d0 = 70 + f.toc_size
+    nch, sfw_back, qs = flofile.parse_transform_blob(flo[d0 + 10:d0 + f.toc[0][2]])
+    assert nch == 2 and list(sfw_back[0]) == sfw
+    assert list(qs[0, 5:8]) == [100, -200, 300] and qs[0, 208] == 7 and int(np.count_nonzero(qs)) == 4
+    pcm, sr, ch = O.decode(flo)
+    assert sr == 44100 and ch == 2 and pcm.size == 2 * 2048 and float(np.max(np.abs(pcm[0::2]))) > 0.01
+    assert not np.any(pcm[1::2])
