@@ -102,6 +102,17 @@ __device__ __forceinline__ float max_abs_raw(float a, float b) {  // max(a, |b|)
     asm("v_max_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// three-way maxima (exact, like max_raw: the hardware returns the non-NaN operand): one instruction where two follow each other
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max3_abs_raw(float a, float b, float c) {  // max(a, |b|, |c|)
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // truncating float -> int conversion as ONE instruction (saturates, NaN -> 0); the C cast would add a v_trunc
 __device__ __forceinline__ int cvt_rz(float x) {
     int r;
@@ -813,7 +824,19 @@ __device__ __forceinline__ float spread_threshold_2(const int lane, float energy
     sm = max_self_dpp<0x108>(sm);
     const float hi0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 16));
     const float hi1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 48));
-    if (b < 16) sm = max_raw(sm, lane < 32 ? hi0 : hi1);
+    // bands 0..15 of either channel also see bands 16..24: two maxima with a scalar operand under the lanes' exec masks (a
+    // select between the two scalars first cost two moves, a compare, a select and a branch)
+    {
+        unsigned long long sv;
+        asm volatile("s_mov_b64 %0, exec\n\t"
+                     "s_mov_b64 exec, 0xffff\n\t"
+                     "v_max_f32 %1, %2, %1\n\t"
+                     "s_mov_b64 exec, %4\n\t"
+                     "v_max_f32 %1, %3, %1\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(sv), "+v"(sm)
+                     : "s"(hi0), "s"(hi1), "s"(0x0000ffff00000000ull));
+    }
     float m = max_raw(-100.0f, sm);
     float cur = band_db;
     const float sd[8] = {sd0.x, sd0.y, sd0.z, sd0.w, sd1.x, sd1.y, sd1.z, sd1.w};
@@ -829,8 +852,12 @@ __device__ __forceinline__ float spread_threshold_2(const int lane, float energy
     }
     const float g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 0));
     const float g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 32));
-    const float gmax = g0 > g1 ? g0 : g1;
-    if (gmax >= 99.0f) {
+    // "some band is at 99 dB or more" on the scalar unit: a float >= 99.0f is positive, and positive floats order like their
+    // bit patterns as signed integers (a negative one, sign bit set, compares below)
+    // (and a NaN, exponent all ones with a mantissa, is not >= 99: 0x7f800000 = +inf is the last pattern that is)
+    const auto loud = [](float g) { const int u = __float_as_int(g); return u >= 0x42c60000 && u <= 0x7f800000; };
+    if (loud(g0) || loud(g1)) {
+        const float gmax = g0 > g1 ? g0 : g1;
         int dmax = 24;
         if (gmax < 500.f) {
             int d = (int)((gmax + 100.0f) * (1.0f / 24.9f)) + 1;
@@ -855,7 +882,9 @@ __device__ __forceinline__ float masking_amplitude(float s, float smr_thr) {
 // scale-factor word (encoder.rs:262-266)
 __device__ __forceinline__ uint32_t sf_word(float sf) {
     if (sf > 1e-10f) {
-        float v = log2f(sf) * 256.0f + 32768.0f;
+        // (sf > 1e-10 here: a normal number, so the library log2f's subnormal pre-scaling - five instructions: compare,
+        // select, ldexp by 0, select, subtract 0 - never acts, and the bare v_log_f32 it ends in gives the same bits)
+        float v = __builtin_amdgcn_logf(sf) * 256.0f + 32768.0f;
         v = fminf(fmaxf(v, 0.0f), 65535.0f);
         return (uint32_t)v;
     }
@@ -992,8 +1021,15 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
         for (int k = 0; k < 4; k++) {
             const int e = 4 * g + k;
             am.xy = fma2(c[e], c[e], am.xy);
-            am.z = max_abs_raw(am.z, c[e].x);
-            am.w = max_abs_raw(am.w, c[e].y);
+            // (where no lane closes a segment at element e - 1, its maximum was left for this step: one three-way maximum)
+            const bool prev_open = e > 0 && !((dirty >> (e - 1)) & 1u), this_open = e < 15 && !((dirty >> e) & 1u);
+            if (prev_open) {
+                am.z = max3_abs_raw(am.z, c[e - 1].x, c[e].x);
+                am.w = max3_abs_raw(am.w, c[e - 1].y, c[e].y);
+            } else if (!this_open) {
+                am.z = max_abs_raw(am.z, c[e].x);
+                am.w = max_abs_raw(am.w, c[e].y);
+            }
             if ((dirty >> e) & 1u) {   // compile-time
 #ifdef FLO_MASKED_SLOTS   // diagnostic: only the lanes that close a segment here store (the others' stores went to per-lane trash slots)
                 if (kp[k] == 0.0f || e == 15) *reinterpret_cast<lds_v4f *>((uintptr_t)(s0 + 2u * dv[k])) = am;
@@ -1015,10 +1051,11 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
 #pragma unroll
         for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const lds_v4f *>((uintptr_t)so[4 * g + u]);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            energy = energy + (v2f){v[u].x, v[u].y};
-            bmax.x = max_raw(bmax.x, v[u].z);
-            bmax.y = max_raw(bmax.y, v[u].w);
+        for (int u = 0; u < 4; u++) energy = energy + (v2f){v[u].x, v[u].y};
+#pragma unroll
+        for (int u = 0; u < 4; u += 2) {
+            bmax.x = max3_raw(bmax.x, v[u].z, v[u + 1].z);
+            bmax.y = max3_raw(bmax.y, v[u].w, v[u + 1].w);
         }
     }
     const int groups = (T.max_band_slots + 7) >> 3;
