@@ -477,6 +477,29 @@ __device__ __forceinline__ void post_rotate_transpose(const int lane, const floa
 // bit-identical to theirs (the kernel forms are compared byte for byte by the tests).
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// (-a) * w.y + (-c) and a * w.y + (-c) on both halves, w.y broadcast by op_sel: the same fused operation as fma2 with a splat
+// of w.y - for the SECOND pair of a 16-byte constant row the compiler copies the component into a fresh register pair
+// first (one v_mov per use site: a dozen per frame in the fold alone), for the first pair it uses op_sel as here.
+__device__ __forceinline__ v2f fma2_na_hi_nc(v2f a, v2f w, v2f c) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,1] neg_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(c));
+    return r;
+}
+__device__ __forceinline__ v2f fma2_a_hi_c(v2f a, v2f w, v2f c) {   // a * w.y + c
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(c));
+    return r;
+}
+__device__ __forceinline__ v2f mul2_hi(v2f a, v2f w) {   // a * w.y on both halves
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(w));
+    return r;
+}
+__device__ __forceinline__ v2f fma2_a_hi_nc(v2f a, v2f w, v2f c) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(c));
+    return r;
+}
 __device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
 
 constexpr int kXch4 = 64 * kXchStride;        // float4 elements of the stereo exchange buffer
@@ -519,6 +542,14 @@ __device__ __forceinline__ void cmul_2(v2f &xr, v2f &xi, float wr, float wi) {
     xr = r;
     xi = i;
 }
+// the same with the twiddle as the SECOND pair (z, w) of a 16-byte row: w.y through the op_sel forms (no copy), identical operations
+__device__ __forceinline__ void cmul_2_pair(v2f &xr, v2f &xi, v2f w) {
+    const v2f WR = splat2(w.x);
+    v2f r = fma2(xr, WR, -mul2_hi(xi, w));
+    v2f i = fma2_a_hi_c(xr, w, xi * WR);
+    xr = r;
+    xi = i;
+}
 
 // fft512 for both channels; x4: kXch4 float4 elements (re0, re1, im0, im1), row stride kXchStride elements
 __device__ __forceinline__ void fft512_2(const int lane, v2f (&zr)[8], v2f (&zi)[8], float4 *x4, const LossyDevTables &T) {
@@ -527,7 +558,7 @@ __device__ __forceinline__ void fft512_2(const int lane, v2f (&zr)[8], v2f (&zi)
     for (int kk = 0; kk < 4; kk++) {
         const float4 w = T.pack[(kRowF1 + kk) * 64 + lane];
         cmul_2(zr[2 * kk + 1], zi[2 * kk + 1], w.x, w.y);
-        if (kk < 3) cmul_2(zr[2 * kk + 2], zi[2 * kk + 2], w.z, w.w);
+        if (kk < 3) cmul_2_pair(zr[2 * kk + 2], zi[2 * kk + 2], (v2f){w.z, w.w});
     }
     {
         const int nb = lane >> 3, nc = lane & 7;
@@ -547,7 +578,7 @@ __device__ __forceinline__ void fft512_2(const int lane, v2f (&zr)[8], v2f (&zi)
     for (int kk = 0; kk < 4; kk++) {
         const float4 w = T.pack[(kRowF2 + kk) * 64 + lane];
         cmul_2(zr[2 * kk + 1], zi[2 * kk + 1], w.x, w.y);
-        if (kk < 3) cmul_2(zr[2 * kk + 2], zi[2 * kk + 2], w.z, w.w);
+        if (kk < 3) cmul_2_pair(zr[2 * kk + 2], zi[2 * kk + 2], (v2f){w.z, w.w});
     }
     {
         const int ka = lane >> 3, nc = lane & 7;
@@ -590,19 +621,27 @@ __device__ __forceinline__ void fold_2(const int lane, const v2f (&ae)[8], const
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const float4 ww = T.pack[(kRowWin + r) * 64 + lane];
-        const v2f wae = splat2(ww.x), wao = splat2(ww.y), wbe = splat2(ww.z), wbo = splat2(ww.w);
+        const v2f wae = splat2(ww.x), wao = splat2(ww.y), wbe = splat2(ww.z);
+        const v2f whi = {ww.z, ww.w};   // (ww.w enters through fma2_na_hi_nc)
         const float4 t4 = T.pack[(kRowTw + (r >> 1)) * 64 + lane];
-        const v2f wx = splat2((r & 1) ? t4.z : t4.x), wy = splat2((r & 1) ? t4.w : t4.y);
+        const v2f wx = splat2((r & 1) ? t4.z : t4.x);
+        const v2f thi = {t4.z, t4.w};
         v2f re, im;
         if (r < 4) {
-            re = fma2(-bo[r], wbo, -(be[r] * wbe));
+            re = fma2_na_hi_nc(bo[r], whi, be[r] * wbe);
             im = fma2(ao[r], wao, -(ae[r] * wae));
         } else {
             re = fma2(-ao[r], wao, ae[r] * wae);
-            im = fma2(-bo[r], wbo, -(be[r] * wbe));
+            im = fma2_na_hi_nc(bo[r], whi, be[r] * wbe);
         }
-        zr[r] = fma2(-im, wy, -(re * wx));
-        zi[r] = fma2(re, wy, -(im * wx));
+        if (r & 1) {
+            zr[r] = fma2_na_hi_nc(im, thi, re * wx);
+            zi[r] = fma2_a_hi_nc(re, thi, im * wx);
+        } else {
+            const v2f wy = splat2(t4.y);
+            zr[r] = fma2(-im, wy, -(re * wx));
+            zi[r] = fma2(re, wy, -(im * wx));
+        }
     }
 }
 
@@ -617,9 +656,17 @@ __device__ __forceinline__ void post_rotate_transpose_2(const int lane, const v2
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const float4 t4 = T.pack[(kRowTw + (r >> 1)) * 64 + lane];
-        const v2f wx = splat2((r & 1) ? t4.z : t4.x), wy = splat2((r & 1) ? t4.w : t4.y);
-        const v2f R = fma2(-zi[r], wy, -(zr[r] * wx));
-        const v2f I = fma2(zi[r], wx, -(zr[r] * wy));
+        const v2f wx = splat2((r & 1) ? t4.z : t4.x);
+        v2f R, I;
+        if (r & 1) {   // (the row's second pair: its .w through the op_sel forms, see fma2_na_hi_nc)
+            const v2f thi = {t4.z, t4.w};
+            R = fma2_na_hi_nc(zi[r], thi, zr[r] * wx);
+            I = fma2(zi[r], wx, -mul2_hi(zr[r], thi));
+        } else {
+            const v2f wy = splat2(t4.y);
+            R = fma2(-zi[r], wy, -(zr[r] * wx));
+            I = fma2(zi[r], wx, -(zr[r] * wy));
+        }
         w0[144 * r] = make_float2(R.x, R.y);
         w1[144 * (7 - r)] = make_float2(I.x, I.y);
     }
