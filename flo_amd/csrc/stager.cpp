@@ -185,11 +185,12 @@ int stager_upload(Stager *s, const std::vector<UploadSeg> &segs, hipStream_t str
         return e ? (size_t)atoi(e) << 20 : kSmallUpload;
     }();
     if (total <= small_limit) {
-        // Several clips: a second thread issues half of the copies on a stream of its own (FLO_UPLOAD_THREADS=1 turns it off).
-        // One pageable copy keeps one staging pipeline of the runtime busy; two in flight come closer to the PCIe rate.
+        // FLO_UPLOAD_THREADS=2: a second thread issues half of the copies on a stream of its own. Measured: 6.2 - 6.9 ms
+        // against 6.8 - 6.9 for 64 x 3.5 MB alone in a process, but 12.0 against 6.5 inside bench.py's process on another
+        // host: the runtime serialises most of it and the extra thread is at the scheduler's mercy. Off by default.
         static const bool two = [] {
             const char *e = getenv("FLO_UPLOAD_THREADS");
-            return !e || atoi(e) >= 2;
+            return e && atoi(e) >= 2;
         }();
         size_t split = segs.size();
         if (two && segs.size() >= 2 && total >= ((size_t)16 << 20)) {
