@@ -32,6 +32,12 @@
 namespace flo {
 
 namespace {
+// ordering point between LDS accesses of ONE wavefront (its LDS instructions execute in order; this pins the compiler)
+__device__ __forceinline__ void wave_sync_l() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
 constexpr int kTileWords = kRiceTileBits / 32;   // 64
 constexpr int kScanTiles = 4;                    // tiles per wavefront in rice_scan at k = 14 (16 entry states); 64 / (k + 2) in general
 constexpr int kScanTilesMax = 32;                // ... at k = 0
@@ -189,6 +195,7 @@ __global__ __launch_bounds__(64) void ll_rice_chain_kernel(LlParArgs A) {
 __global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
     // 64 tiles of 64 words; one pad word per tile so that lanes at the same offset of their tiles hit 64 banks
     __shared__ uint32_t words[64 * (kTileWords + 1) + kDecOver + 4];
+    __shared__ uint32_t stg[64 * 17], s_cnt[64], s_base[64];   // 16 pending values per lane (one pad word per row), their count and place
     const unsigned ch = blockIdx.x;
     const unsigned first = A.tile0[ch], nt = A.tile0[ch + 1] - first;
     const unsigned t0 = blockIdx.y * 64u;
@@ -199,8 +206,8 @@ __global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
     stage_words(p, c.len, t0 * kTileWords, 64 * kTileWords + kDecOver, lane, [&](int i, uint32_t v) { words[i + (i >> 6)] = v; });
     __syncthreads();
     const unsigned t = t0 + lane;
-    if (t >= nt) return;
-    const uint2 e = A.tile_entry[first + t];
+    const bool have_tile = t < nt;   // (lanes without a tile stay for the cooperative stores)
+    const uint2 e = have_tile ? A.tile_entry[first + t] : make_uint2(0u, 0u);
     const uint32_t k = c.rice_k, n = c.samples;
     int *out = A.scratch + c.out_off;
     // bit positions are relative to the wavefront's first tile; word i lives at words[i + i / 64]
@@ -216,7 +223,25 @@ __global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
     // tile (or the tile holds no code start at all) and produces no value here.
     bool skip = e.y == k + 1u, active = true, escape = false;
     uint32_t pos = tile_lo + (skip ? 0u : e.y), idx = e.x, q = 0;
-    active = skip || (pos < tile_hi && idx < n);
+    active = have_tile && (skip || (pos < tile_hi && idx < n));
+    // A lane's values go to consecutive places of ITS tile's run: written one at a time, a store instruction touched 64
+    // different lines (4 bytes each) and the kernel ran at the pace of the store path. They are collected in LDS - at
+    // most one per lane and iteration, sixteen iterations at a time - and written out four rows per instruction, a row
+    // = up to 16 consecutive values of one lane.
+    uint32_t pend = 0, pbase = idx, it = 0;
+    auto flush = [&]() {
+        s_cnt[lane] = pend;
+        s_base[lane] = pbase;
+        wave_sync_l();
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int row = 4 * j + (lane >> 4), col = lane & 15;
+            if ((uint32_t)col < s_cnt[row]) out[s_base[row] + (uint32_t)col] = (int)stg[row * 17 + col];
+        }
+        wave_sync_l();
+        pend = 0;
+        pbase = idx;
+    };
     while (__ballot(active) != 0ull) {
         const uint32_t rp = active ? pos : tile_lo;
         const uint32_t ones = leading_ones(win(rp));
@@ -230,7 +255,8 @@ __global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
         const bool emit = active && term && !skip && !esc;
         if (emit) {
             const uint32_t u = (q2 << k) | rem;
-            out[idx] = (int)(u >> 1) ^ -(int)(u & 1u);
+            stg[lane * 17 + (int)pend] = (uint32_t)((int)(u >> 1) ^ -(int)(u & 1u));
+            pend++;
         }
         const uint32_t npos = term ? z + 1u + k : z;
         const uint32_t nidx = idx + (emit ? 1u : 0u);
@@ -241,7 +267,9 @@ __global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
         q = term ? 0u : q2;
         skip = skip && !term;
         active = active && go_on;
+        if ((++it & 15u) == 0u) flush();   // (uniform)
     }
+    flush();
     if (escape) A.serial[ch] = 1;
 }
 
