@@ -932,7 +932,7 @@ __device__ __forceinline__ uint32_t sf_word(float sf) {
         // (sf > 1e-10 here: a normal number, so the library log2f's subnormal pre-scaling - five instructions: compare,
         // select, ldexp by 0, select, subtract 0 - never acts, and the bare v_log_f32 it ends in gives the same bits)
         float v = __builtin_amdgcn_logf(sf) * 256.0f + 32768.0f;
-        v = fminf(fmaxf(v, 0.0f), 65535.0f);
+        v = __builtin_amdgcn_fmed3f(v, 0.0f, 65535.0f);   // clamp (v is a number here: one instruction instead of max + min)
         return (uint32_t)v;
     }
     return 0u;

@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         // masking level, temporal step and scale factors of both channels in one pass: channel 0 on lanes 0..24, channel 1
         // on lanes 32..56 (band_stats_2 leaves every band's totals in both halves)
         const int bnd = ln & 31, up = ln >> 5;
-        const float rcount = T.pack[kRowLane * 64 + bnd].z;
+        const float rcount = T.pack[kRowLane * 64 + ln].z;   // (the row holds band (lane & 31)'s value on every lane)
         uint32_t sfw1;
         {
             const float a = spread_threshold_2(ln, energy1, rcount, T);
@@ -1039,8 +1039,12 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
             const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
             sfw1 = sf_word(sfv1);
             if (bnd < 25) {
-                reinterpret_cast<float *>(&lds.u.a.ts[bnd])[up] = tl1;
-                reinterpret_cast<float *>(&lds.u.a.ts[bnd])[2 + up] = sfv1;
+                // (a scalar base + two shift-adds: as base + member offset + two products the address took four instructions)
+                typedef __attribute__((address_space(3))) float lds_f32;
+                const uint32_t ts_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds.u.a.ts);
+                lds_f32 *tp = reinterpret_cast<lds_f32 *>((uintptr_t)(ts_s + 16u * (uint32_t)bnd + 4u * (uint32_t)up));
+                tp[0] = tl1;
+                tp[2] = sfv1;
             }
         }
         wave_sync();
