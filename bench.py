@@ -241,7 +241,7 @@ def main():
 
     # the dominant kernel is whichever chain form ran (auto picks the three-wave pipeline for stereo batches)
     kname, k_ms, k_n = "lossy_frames", 0.0, 0
-    for cand in ("lossy_chain2x", "lossy_chain3", "lossy_chain", "lossy_frames"):
+    for cand in ("lossy_chain2q", "lossy_chain2x", "lossy_chain3", "lossy_chain", "lossy_frames"):
         ms, n = ctx.profile_query(cand)
         if n:
             kname, k_ms, k_n = cand, ms, n
@@ -283,7 +283,7 @@ def main():
                                      "HBM); its 1250-clip shard is timed under shard_1250, configs[1] (one 3-min clip) under "
                                      "single_clip_180s" if args.clips_per_gpu == 10000 and args.clip_seconds == 10.0 else ""),
             "clips_per_gpu": args.clips_per_gpu, "clip_seconds": args.clip_seconds, "quality": args.quality,
-            "kernel_form": {"lossy_chain2x": "chain, one lock-step stereo transform wave + one packer wave per clip", "lossy_chain3": "chain, three waves per stereo clip", "lossy_chain": "chain, one wave per channel", "lossy_frames": "frame-parallel"}[kname],
+            "kernel_form": {"lossy_chain2q": "chain, one lock-step stereo transform wave + one quantiser-and-packer wave per clip", "lossy_chain2x": "chain, one lock-step stereo transform wave (with the quantiser) + one packer wave per clip", "lossy_chain3": "chain, three waves per stereo clip", "lossy_chain": "chain, one wave per channel", "lossy_frames": "frame-parallel"}[kname],
             "compressed_bytes_per_gpu": data_bytes,
         },
     }

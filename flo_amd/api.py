@@ -215,8 +215,8 @@ class Context:
         return dict(q=q, sf_words=sfw)
 
     def sparse_pack(self, q, form=0):
-        """serialize_sparse on the device. form 0: as the encoder packs (block form, general form for dense vectors);
-        form 1: the general form for every vector."""
+        """serialize_sparse on the device. form 0: as the encoder packs (item form, behind it the block form, behind that the
+        general form for dense vectors); form 1: the general form for every vector; form 2: block form, then general."""
         q = np.ascontiguousarray(q, np.int16).reshape(-1, 1024)
         n = q.shape[0]
         out = np.zeros(n * 2080, np.uint8)

@@ -153,7 +153,7 @@ extern "C" int flo_ctx_device_info(const flo_ctx *c, char *name, size_t cap, int
 }
 extern "C" void *flo_ctx_stream(flo_ctx *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int flo_ctx_force_path(flo_ctx *c, int which) {
-    if (!c || which < 0 || which > 4) return FLO_ERR_ARG;
+    if (!c || which < 0 || which > 5) return FLO_ERR_ARG;
     c->force_path = which;
     return FLO_OK;
 }
@@ -537,7 +537,8 @@ extern "C" int flo_batch_fill_synthetic(flo_batch *b, uint32_t seed, uint64_t cl
 // auto selection of the lossy kernel form (flo_batch_encode with which = 0 and nothing forced)
 static int auto_form(const flo_batch *b) {
     if (b->ch > 2) return 2;
-    return (b->n_clips * b->ch >= 512) ? (b->ch == 2 ? 4 : 1) : 2;
+    static const int stereo_chain = [] { const char *e = getenv("FLO_CHAIN2Q"); return e && atoi(e) == 0 ? 4 : 5; }();
+    return (b->n_clips * b->ch >= 512) ? (b->ch == 2 ? stereo_chain : 1) : 2;
 }
 // scratch of the frame-parallel form: per-frame masking levels, fixed-size frame slots, frame offsets
 static int alloc_frame_scratch(flo_batch *b) {
@@ -590,7 +591,7 @@ static int batch_encode_launch(flo_batch *b, int which);
 extern "C" int flo_batch_encode(flo_batch *b, int which) {
     if (!b) return FLO_ERR_ARG;
     flo_ctx *c = b->ctx;
-    if (which < 0 || which > 4) return fail(c, FLO_ERR_ARG, "unknown kernel form");
+    if (which < 0 || which > 5) return fail(c, FLO_ERR_ARG, "unknown kernel form");
     HIPCHK(c, hipSetDevice(c->device));
     // "encoded" is set only once every launch of this call has been accepted: after a failed encode, sync / fetch /
     // pack refuse with FLO_ERR_STATE instead of handing out stale or partial bytes
@@ -621,15 +622,22 @@ static int batch_encode_launch(flo_batch *b, int which) {
     if (which == 0) which = auto_form(b);
     if (b->ch > 2) which = 2;   // more than two channels: the generic frame-parallel kernels
     int rc;
-    if (which == 4 && b->exact) which = 3;
-    if (which == 4 && b->ch == 2) {   // stereo: one lock-step transform wave + one packer wave per clip
+    if ((which == 4 || which == 5) && b->exact) which = 3;
+    if (which == 5 && b->ch == 2) {   // stereo: transform wave + (quantiser and packer) wave per clip
+#ifdef FLO_STAMPS
+        if (!b->d_stamps) HIPCHK(c, pool_alloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
+#endif
+        LossyArgs A = make_args(b);
+        HIPCHK(c, hipMemsetAsync(b->d_next, 0, 4, c->stream));   // the batch-wide clip counter of the persistent workgroups
+        rc = timed_launch(c, "lossy_chain2q", [&] { return launch_lossy_chain2q(A, c->stream); });
+    } else if (which == 4 && b->ch == 2) {   // stereo: one lock-step transform wave + one packer wave per clip
 #ifdef FLO_STAMPS
         if (!b->d_stamps) HIPCHK(c, pool_alloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
 #endif
         LossyArgs A = make_args(b);
         HIPCHK(c, hipMemsetAsync(b->d_next, 0, 4, c->stream));   // the batch-wide clip counter of the persistent workgroups
         rc = timed_launch(c, "lossy_chain2x", [&] { return launch_lossy_chain2x(A, c->stream); });
-    } else if (which == 1 || ((which == 3 || which == 4) && b->ch != 2)) {
+    } else if (which == 1 || ((which == 3 || which == 4 || which == 5) && b->ch != 2)) {
 #ifdef FLO_STAMPS
         if (!b->d_stamps) HIPCHK(c, pool_alloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
 #endif
@@ -710,17 +718,17 @@ static int batch_sync_impl(flo_batch *b, hipEvent_t done) {
                 for (size_t w = 0; w < b->n_clips * b->ch; w++)
                     for (int i = 0; i < 14; i++) sum[i] += (double)st[w * 16 + i];
                 double frames = (double)b->total_frames * b->ch;
-                if (b->ch == 2 && (c->force_path == 4 || c->force_path == 0)) {   // lock-step form: wave 0 = transform, wave 1 = packer
+                if (b->ch == 2 && (c->force_path == 4 || c->force_path == 5 || c->force_path == 0)) {   // lock-step forms: wave 0 = transform, wave 1 = packer
                     double t[14] = {0}, p[14] = {0};
                     for (size_t k = 0; k < b->n_clips; k++)
                         for (int i = 0; i < 14; i++) { t[i] += (double)st[(2 * k) * 16 + i]; p[i] += (double)st[(2 * k + 1) * 16 + i]; }
                     static const char *tn[] = {"fold", "prefetch", "fft", "postrot", "bandstats", "mask", "quant", "wait-consumed", "handover"};
-                    static const char *pn[] = {"wait-ready", "read", "pack0", "pack1", "flush"};
+                    static const char *pn[] = {"wait-ready", "read/quant", "pack0", "pack1", "flush", "wait-ts"};
                     fprintf(stderr, "[stamps2x] ticks (10 ns) per stereo frame | T:");
                     double tt = 0, pt = 0;
                     for (int i = 0; i < 9; i++) { fprintf(stderr, " %s=%.1f", tn[i], t[i] / b->total_frames); tt += t[i]; }
                     fprintf(stderr, " total=%.1f | P:", tt / b->total_frames);
-                    for (int i = 0; i < 5; i++) { fprintf(stderr, " %s=%.1f", pn[i], p[i] / b->total_frames); pt += p[i]; }
+                    for (int i = 0; i < 6; i++) { fprintf(stderr, " %s=%.1f", pn[i], p[i] / b->total_frames); pt += p[i]; }
                     fprintf(stderr, " total=%.1f", pt / b->total_frames);
                     fprintf(stderr, " | T waits>1000: %.2f%% of frames, %.0f cyc/frame avg; >5000: %.2f%%, %.0f | P busy>12000: %.2f%%, %.0f; >20000: %.2f%%, %.0f\n",
                             100 * t[10] / b->total_frames, t[9] / b->total_frames, 100 * t[12] / b->total_frames, t[11] / b->total_frames,
@@ -1209,7 +1217,7 @@ extern "C" int flo_lossy_quantize(flo_ctx *c, const float *coeffs, size_t num_ho
 
 extern "C" int flo_sparse_pack(flo_ctx *c, const int16_t *q, size_t n_vec, int form, uint8_t *out, size_t out_cap,
                                uint32_t *out_off) {
-    if (!c || (n_vec && (!q || !out || !out_off)) || form < 0 || form > 1) return FLO_ERR_ARG;
+    if (!c || (n_vec && (!q || !out || !out_off)) || form < 0 || form > 2) return FLO_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (out_off) out_off[0] = 0;
     if (!n_vec) return FLO_OK;

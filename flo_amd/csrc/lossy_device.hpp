@@ -1031,7 +1031,7 @@ struct StereoLds {
 // two halves of a band meet through ONE swap per quantity that also sorts the channels: the result has channel 0's
 // band b on lane b and channel 1's on lane 32 + b, which is what the merged masking pass consumes.
 template <uint32_t DIRTY = 0xFFFFu>
-__device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16], StereoLds &L, const LossyDevTables &T,
+__device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16], float4 *slot, const LossyDevTables &T,
                                              float &energy1, float &bmax1) {
     // Slot addresses as 32-bit LDS offsets from ONE scalar base (as the sum of the clip's LDS base and the member offset
     // the compiler re-added both terms for every access); the accesses go through address-space-3 pointers so that they
@@ -1040,7 +1040,7 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
     // table rows hold 8-byte-slot offsets (shared with band_stats<CH>), hence the factor 2.
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) v4f lds_v4f;
-    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)L.u.a.slot);
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)slot);
     // the zero slot shares storage with the exchange buffer: written every frame (lane l writes dword l & 3: no branch, one
     // register of zeros, a 4-byte store instead of a 16-byte one)
     {
@@ -1191,6 +1191,70 @@ __device__ __forceinline__ void quantise_2(const int lane, const v2f (&c)[16], c
                     : "vcc");
                 xs[ch][2 * g + k2] = r;
             }
+    }
+}
+
+// The quantiser in the packer wave's NATURAL layout (lossy_chain2q_kernel). cf[k] = (left, right) of position 128 k + 2 lane,
+// (left, right) of the position behind it: one 16-byte read per block straight out of the transform wave's coefficient
+// buffer. ts_a[e] = LDS byte address of the float4 (threshold left, right | scale factor left, right) of the band of entry
+// e = 2 k + j (TSOFF selects the frame parity's table through the instruction offset), athn[e] = its ATH amplitude threshold.
+// Every coefficient goes through exactly the operations of quantise_2 - same product, same rounding constant, same
+// truncating conversion, same comparison - so the integers are identical. xd[ch][k] = the i16 of the two positions (even
+// position in the low half): the dword sparse_block_pack takes, no re-dealing.
+typedef float v4f __attribute__((ext_vector_type(4)));
+// alive: bit b set when band b of either channel holds a coefficient above its masking amplitude (the transform wave's
+// ballot of band maximum > threshold); blk[k]: the bands block k has bins of. A block none of whose bands is alive keeps
+// nothing - the keep test is |c| > max(band threshold, ATH) - and is not quantised at all: its dwords are zero.
+template <int TSOFF>
+__device__ __forceinline__ void quantise_nat(const v4f (&cf)[8], const uint32_t (&ts_a)[16], const float (&athn)[16],
+                                             const uint32_t alive, const uint32_t (&blk)[8], uint32_t (&xd)[2][8]) {
+    typedef __attribute__((address_space(3))) v4f lds_f4;
+    const uint32_t sgn_mask = 0x7FFFFFFFu;
+    uint32_t phalf = 0x3EFFFFFFu;
+    asm volatile("" : "+v"(phalf));   // kept in a register: a VOP3 operand cannot be a literal
+    // one block: positions 128 k + 2 lane and + 1 of both channels against the tables t0 / t1 of their bands
+    auto block = [&](const int k, const v4f t0, const v4f t1, uint32_t &out0, uint32_t &out1) __attribute__((always_inline)) {
+        const v2f x0 = {cf[k].x, cf[k].y}, x1 = {cf[k].z, cf[k].w};
+        const v2f s0 = x0 * (v2f){t0.z, t0.w}, s1 = x1 * (v2f){t1.z, t1.w};
+        uint32_t h00, h01, h10, h11;
+        // sign of the product = sign of the coefficient (scale factors are positive): no wait for the multiplication
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(h00) : "s"(sgn_mask), "v"(phalf), "v"(x0.x));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(h01) : "s"(sgn_mask), "v"(phalf), "v"(x0.y));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(h10) : "s"(sgn_mask), "v"(phalf), "v"(x1.x));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(h11) : "s"(sgn_mask), "v"(phalf), "v"(x1.y));
+        const v2f r0 = s0 + (v2f){__uint_as_float(h00), __uint_as_float(h01)};
+        const v2f r1 = s1 + (v2f){__uint_as_float(h10), __uint_as_float(h11)};
+        const int v0[2] = {cvt_rz(r0.x), cvt_rz(r0.y)}, v1[2] = {cvt_rz(r1.x), cvt_rz(r1.y)};
+        const float a0 = athn[2 * k], a1 = athn[2 * k + 1];
+        const float th0[2] = {max_raw(t0.x, a0), max_raw(t0.y, a0)}, th1[2] = {max_raw(t1.x, a1), max_raw(t1.y, a1)};
+        uint32_t r[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            const float xe = ch ? x0.y : x0.x, xo = ch ? x1.y : x1.x;
+            // keep iff |c| > thr (a NaN coefficient compares false like the reference, and converted to 0 anyway)
+            asm("v_cmp_gt_f32_e64 vcc, |%1|, %2\n\t"
+                "v_cndmask_b32_e32 %0, 0, %3, vcc\n\t"
+                "v_cmp_gt_f32_e64 vcc, |%4|, %5\n\t"
+                "v_cndmask_b32_sdwa %0, 0, %6, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                : "=&v"(r[ch])
+                : "v"(xe), "v"(th0[ch]), "v"(v0[ch]), "v"(xo), "v"(th1[ch]), "v"(v1[ch])
+                : "vcc");
+        }
+        out0 = r[0];
+        out1 = r[1];
+    };
+#pragma unroll
+    for (int g = 0; g < 4; g++) {   // two blocks, four gathers in flight
+        uint32_t o00 = 0u, o01 = 0u, o10 = 0u, o11 = 0u;   // [block of the pair][channel]
+        if (alive & (blk[2 * g] | blk[2 * g + 1])) {   // uniform
+            v4f tb[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) tb[j] = *reinterpret_cast<const lds_f4 *>((uintptr_t)(ts_a[4 * g + j] + (uint32_t)TSOFF));
+            if (alive & blk[2 * g]) block(2 * g, tb[0], tb[1], o00, o01);
+            if (alive & blk[2 * g + 1]) block(2 * g + 1, tb[2], tb[3], o10, o11);
+        }
+        xd[0][2 * g] = o00, xd[1][2 * g] = o01;
+        xd[0][2 * g + 1] = o10, xd[1][2 * g + 1] = o11;
     }
 }
 
@@ -1512,6 +1576,163 @@ __device__ __forceinline__ uint32_t sparse_block_pack(const int lane, const uint
             }
         }
         tot += cz >= 128u ? 3u : 2u;
+    }
+    return tot;
+}
+
+// ------------------------------------------------------------------------------------------------ sparse RLE, item form
+// serialize_sparse (encoder.rs:284-314) for the frames a q <= 0.8 encode is made of: a few dozen non-zeros in 1024 values.
+// The block form above does per block of 128 POSITIONS what this form does per NON-ZERO:
+//   1. compaction: per non-empty block two ballots and one rank (v_mbcnt) put every non-zero, in position order, into a
+//      list in LDS as (position + 1) << 16 | value - one dword store per half, nothing else;
+//   2. item pass: lane i takes items i and i + 64 and their predecessors (entry 0 of the list is a sentinel at "position
+//      -1"). The zero run in front of an item is a subtraction; "starts a record" and "record with a two-byte varint" are
+//      two compares whose ballots give, by v_mbcnt, the records and wide records up to the item, hence its byte offset
+//      2 i + 2 records + wide; a record's count byte is the distance to the next record start, looked up through a
+//      table "first item of record r" the starting lanes fill. No loop over positions, blocks or records.
+// Up to kItemCap non-zeros (more: kSparseFallback, nothing usable written - the caller takes the block form); a run of
+// non-zeros therefore never reaches 255 and no continuation records exist here.
+// tabp: LDS byte address of kPackTabDwords dwords (item list, then the record table).
+constexpr int kItemCap = 128;
+constexpr int kItemTbl = 136;          // dword offset of the record table inside the area
+constexpr int kPackTabDwords = 272;
+__device__ __forceinline__ uint32_t sparse_item_pack(const int lane, const uint32_t (&xd)[8], const uint32_t blob, const uint32_t tabp) {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    const uint32_t list1 = tabp + 4u;   // item r at list1 + 4 r
+    const uint32_t pk0 = (uint32_t)(2 * lane + 1) << 16;   // (position + 1) << 16 of the lane's even position in block 0
+    if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(tabp), "v"(0u) : "memory");   // the sentinel
+    uint32_t nM = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        unsigned long long E;
+        asm("v_cmp_ne_u16_e64 %0, 0, %1" : "=s"(E) : "v"(xd[k]));
+        const unsigned long long O = __ballot(xd[k] > 0xFFFFu);
+        if ((E | O) == 0ull) continue;   // uniform: 128 zeros
+        // rank of the lane's even position: non-zeros so far + those of lower lanes (both halves); the odd position follows it.
+        // Clamped to the list's capacity: a vector with more non-zeros than that is declined behind the loop (one exit
+        // instead of a test per block), and what its late blocks wrote is never read.
+        uint32_t re = __builtin_amdgcn_mbcnt_hi((uint32_t)(O >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)O,
+                      __builtin_amdgcn_mbcnt_hi((uint32_t)(E >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)E, nM))));
+        re = re < (uint32_t)kItemCap ? re : (uint32_t)kItemCap;
+        const uint32_t a_e = (re << 2) + list1;
+        uint32_t e4;
+        asm("v_cndmask_b32_e64 %0, 0, 4, %1" : "=v"(e4) : "s"(E));
+        const uint32_t a_o = a_e + e4;
+        const uint32_t pk_e = pk0 + ((uint32_t)k << 23);
+        uint32_t it_e;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(it_e) : "s"(0xFFFFu), "v"(xd[k]), "v"(pk_e));
+        const uint32_t it_o = __builtin_amdgcn_perm(pk_e + 0x10000u, xd[k], 0x07060302u);   // (pos + 2) << 16 | high halfword
+        unsigned long long sv;
+        asm volatile("s_mov_b64 %0, exec\n\t"
+                     "s_mov_b64 exec, %1\n\tds_write_b32 %3, %4\n\t"
+                     "s_mov_b64 exec, %2\n\tds_write_b32 %5, %6\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(sv)
+                     : "s"(E), "s"(O), "v"(a_e), "v"(it_e), "v"(a_o), "v"(it_o)
+                     : "memory");
+        nM += (uint32_t)__builtin_popcountll(E) + (uint32_t)__builtin_popcountll(O);
+    }
+    const uint32_t N = nM;
+    if (N > (uint32_t)kItemCap) return kSparseFallback;
+    wave_sync();
+    const uint32_t vaddr = tabp + 4u * (uint32_t)lane;
+    const uint32_t tblp = tabp + 4u * (uint32_t)kItemTbl;
+    const uint32_t lane2 = 2u * (uint32_t)lane;
+    const uint32_t b3 = blob - 3u;
+    const bool two = N > 64u;   // uniform
+    // ---- first 64 items
+    const uint32_t prevA = *reinterpret_cast<const lds_u32 *>((uintptr_t)vaddr), itA = *reinterpret_cast<const lds_u32 *>((uintptr_t)(vaddr + 4u));
+    uint32_t diffA;   // (position of the item) - (position of its predecessor) = zero run + 1
+    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(diffA) : "v"(itA), "v"(prevA));
+    const unsigned long long maskA = N >= 64u ? ~0ull : ((1ull << N) - 1ull);
+    const unsigned long long SmA = (__ballot(diffA != 1u) | 1ull) & maskA;   // the walk's first record starts on item 0 whatever precedes it
+    const unsigned long long WmA = __ballot(diffA >= 129u) & SmA;
+    uint32_t ownA, ownWA;
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(ownA) : "s"(SmA));
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(ownWA) : "s"(WmA));
+    const uint32_t rA = __builtin_amdgcn_mbcnt_hi((uint32_t)(SmA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)SmA, ownA));
+    const uint32_t wA = __builtin_amdgcn_mbcnt_hi((uint32_t)(WmA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)WmA, ownWA));
+    const uint32_t baseA = ((rA << 1) + wA) + (lane2 + b3);
+    const uint32_t RA = (uint32_t)__builtin_popcountll(SmA), WA = (uint32_t)__builtin_popcountll(WmA);
+    {
+        unsigned long long sv;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+                     : "=&s"(sv) : "s"(SmA), "v"((rA << 2) + tblp), "v"((uint32_t)lane) : "memory");
+    }
+    // ---- items 64..127
+    uint32_t itB = 0, diffB = 1, rB = 0, baseB = 0, RB = 0, WB = 0;
+    unsigned long long maskB = 0, SmB = 0, WmB = 0;
+    if (two) {
+        const uint32_t prevB = *reinterpret_cast<const lds_u32 *>((uintptr_t)(vaddr + 256u));
+        itB = *reinterpret_cast<const lds_u32 *>((uintptr_t)(vaddr + 260u));
+        asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(diffB) : "v"(itB), "v"(prevB));
+        maskB = N >= 128u ? ~0ull : ((1ull << (N - 64u)) - 1ull);
+        SmB = __ballot(diffB != 1u) & maskB;
+        WmB = __ballot(diffB >= 129u) & SmB;
+        uint32_t ownB, ownWB;
+        asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(ownB) : "s"(SmB));
+        asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(ownWB) : "s"(WmB));
+        rB = __builtin_amdgcn_mbcnt_hi((uint32_t)(SmB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)SmB, ownB + RA));
+        const uint32_t wB = __builtin_amdgcn_mbcnt_hi((uint32_t)(WmB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)WmB, ownWB + WA));
+        baseB = ((rB << 1) + wB) + (lane2 + (b3 + 128u));
+        RB = (uint32_t)__builtin_popcountll(SmB), WB = (uint32_t)__builtin_popcountll(WmB);
+        unsigned long long sv;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+                     : "=&s"(sv) : "s"(SmB), "v"((rB << 2) + tblp), "v"((uint32_t)lane + 64u) : "memory");
+    }
+    const uint32_t R = RA + RB, Wd = WA + WB;
+    if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(tblp + 4u * (R + 1u)), "v"(N) : "memory");   // "the record after the last" starts at item N
+    wave_sync();
+    // ---- bytes: values at base + 3, + 4; a record's header in front of its first value: base + 1 = zero run (or the
+    // varint's second byte behind base + 0 = its first), base + 2 = count
+    {
+        const uint32_t nxt = *reinterpret_cast<const lds_u32 *>((uintptr_t)((rA << 2) + tblp + 4u));
+        const uint32_t cnt = nxt - (uint32_t)lane;
+        const uint32_t gap = diffA - 1u;
+        const uint32_t h0 = (gap & 0x7Fu) | 0x80u;
+        uint32_t h1;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(h1) : "v"(gap), "v"(gap >> 7), "s"(WmA));
+        const uint32_t v8 = itA >> 8;
+        unsigned long long sv;
+        asm volatile("s_mov_b64 %0, exec\n\t"
+                     "s_mov_b64 exec, %1\n\tds_write_b8 %4, %5 offset:3\n\tds_write_b8 %4, %6 offset:4\n\t"
+                     "s_mov_b64 exec, %2\n\tds_write_b8 %4, %8 offset:1\n\tds_write_b8 %4, %9 offset:2\n\t"
+                     "s_mov_b64 exec, %3\n\tds_write_b8 %4, %7\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(sv)
+                     : "s"(maskA), "s"(SmA), "s"(WmA), "v"(baseA), "v"(itA), "v"(v8), "v"(h0), "v"(h1), "v"(cnt)
+                     : "memory");
+    }
+    uint32_t last = itA;
+    if (two) {
+        const uint32_t nxt = *reinterpret_cast<const lds_u32 *>((uintptr_t)((rB << 2) + tblp + 4u));
+        const uint32_t cnt = nxt - ((uint32_t)lane + 64u);
+        const uint32_t gap = diffB - 1u;
+        const uint32_t h0 = (gap & 0x7Fu) | 0x80u;
+        uint32_t h1;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(h1) : "v"(gap), "v"(gap >> 7), "s"(WmB));
+        const uint32_t v8 = itB >> 8;
+        unsigned long long sv;
+        asm volatile("s_mov_b64 %0, exec\n\t"
+                     "s_mov_b64 exec, %1\n\tds_write_b8 %4, %5 offset:3\n\tds_write_b8 %4, %6 offset:4\n\t"
+                     "s_mov_b64 exec, %2\n\tds_write_b8 %4, %8 offset:1\n\tds_write_b8 %4, %9 offset:2\n\t"
+                     "s_mov_b64 exec, %3\n\tds_write_b8 %4, %7\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(sv)
+                     : "s"(maskB), "s"(SmB), "s"(WmB), "v"(baseB), "v"(itB), "v"(v8), "v"(h0), "v"(h1), "v"(cnt)
+                     : "memory");
+        last = itB;
+    }
+    // closing record of the zeros behind the last non-zero: [varint zeros][0] (all 1024 when there is none: 80 08 00)
+    uint32_t tot = 2u * (N + R) + Wd;
+    const uint32_t pf_last = N ? ((uint32_t)__builtin_amdgcn_readlane((int)last, (int)((N - 1u) & 63u)) >> 16) : 0u;
+    const uint32_t cz = 1024u - pf_last;
+    {   // bytes [cz][0] or [cz & 0x7f | 0x80][cz >> 7][0] as a word, lane i < its length stores byte i
+        const uint32_t wide = cz >= 128u ? 1u : 0u;
+        const uint32_t word = wide ? (((cz & 0x7Fu) | 0x80u) | ((cz >> 7) << 8)) : cz;
+        const uint32_t len = cz ? 2u + wide : 0u;
+        if ((uint32_t)lane < len) lds_st8_at(blob + tot + (uint32_t)lane, word >> (8u * (uint32_t)lane), 0);
+        tot += len;
     }
     return tot;
 }

@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
         // band statistics, masking level, temporal masking, scale factors (analyse_frame, both channels)
         float energy1, bmax1;   // channel 0's band b on lane b, channel 1's on lane 32 + b
 #if (FLO_SKIP & 1) == 0
-        band_stats_2<DIRTY>(ln, c, lds, T, energy1, bmax1);
+        band_stats_2<DIRTY>(ln, c, lds.u.a.slot, T, energy1, bmax1);
 #else
         energy1 = c[0].x + c[5].y;
         bmax1 = c[1].x + c[7].y;
@@ -1111,6 +1111,372 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArg
 #endif
     fbase += hops;
     }   // next clip
+}
+
+// ---------------------------------------------------------------------------------------------- two waves per clip, the packer quantises
+// The same pair of waves per stereo clip as lossy_chain2x_kernel with the work divided differently: the TRANSFORM wave
+// stops after the masking pass (fold, FFT, post-rotation, band statistics, masking level, scale factors) and the PACKER
+// wave quantises. Twelve waves land round-robin on four SIMDs, so two SIMDs hold (transform, transform, packer) and
+// two hold (transform, packer, packer); with the quantiser in the transform wave the first kind carried 1941 vector
+// instructions per frame round against 1350 and set the launch time. What crosses the waves:
+//   * the f32 coefficients, which are NOT copied: the packer reads them (one 16-byte read per block of 128 positions, in
+//     the layout its sparse packer wants: no re-dealing of integers either) out of the transposition buffer the
+//     post-rotation left them in, as soon as `coef_ready` says so, and answers `consumed`; the transform wave needs the
+//     buffer again for the first FFT exchange of the NEXT frame, after that frame's fold and prefetch;
+//   * 25 x (threshold amplitude, scale factor) per channel and the scale words, in tables of their own chosen by frame
+//     parity (`ts_ready`): the packer may still be reading frame h - 1's while frame h's are written.
+// The quantiser's per-position constants (ATH thresholds, band offsets) live in the packer's registers for the whole
+// launch (rows kRowAthN / kRowBoN, read from global memory once): they leave the LDS pack, and so does the i16 hand-over.
+struct Clip2qLds {
+    union {
+        float4 xch4[kXch4];      // FFT exchanges
+        float2 coef2[kCoef2];    // coefficient k of both channels at element k + 2 (k >> 4): written by the post-rotation, read by both waves
+    } u;
+    float4 slot[kSlots];         // band-statistics slots (see band_stats_2)
+    float4 ts[2][32];            // [frame parity][band]: amplitude thresholds (left, right), scale factors (left, right)
+    __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 256];
+    uint16_t sfwh[2][2][32];     // [frame parity][channel][band] scale words
+    uint32_t alive[2][2];        // [frame parity][channel]: bit b = band b holds a coefficient above its masking amplitude
+    uint32_t pad2[4];
+    uint32_t packtab[kPackTabDwords];     // item list + record table of the item-form packer / run table of the block form
+    uint32_t coef_ready;         // frames whose coefficients are in coef2
+    uint32_t ts_ready;           // frames whose band tables are published
+    uint32_t consumed;           // frames whose coefficients the packer has taken
+    uint32_t clip_seq;           // clips handed to the transform wave so far ...
+    uint32_t clip_cur;           // ... and the latest one
+    uint32_t pad[3];
+};
+static_assert(sizeof(Clip2qLds) % 16 == 0, "clip LDS block keeps 16-byte alignment");
+constexpr int kPackBytesHotT = kPackRowsHotT * 64 * 16;
+
+template <bool COEFFS, uint32_t DIRTY, bool DBG>
+__global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArgs A, int clips_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    {
+        float4 *dstp = reinterpret_cast<float4 *>(lds_raw);
+        for (int i = tid; i < kPackRowsHotT * 64; i += (int)blockDim.x) dstp[i] = A.T.pack[i];
+        for (int i = tid; i < clips_per_wg; i += (int)blockDim.x) {
+            Clip2qLds &c0 = *reinterpret_cast<Clip2qLds *>(lds_raw + kPackBytesHotT + (size_t)i * sizeof(Clip2qLds));
+            c0.coef_ready = 0;
+            c0.ts_ready = 0;
+            c0.consumed = 0;
+            c0.clip_seq = 0;
+        }
+    }
+    __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // waves 0 .. g-1 are the transform waves, waves g .. 2g-1 the packers
+    const int cl = wv % clips_per_wg;
+    Clip2qLds &cs = *reinterpret_cast<Clip2qLds *>(lds_raw + kPackBytesHotT + (size_t)cl * sizeof(Clip2qLds));
+    // Persistent workgroups, clips dealt dynamically (see lossy_chain2x_kernel): the packer claims, frame counters run on
+    // across clips. The two roles are two separate loops so that neither's registers are live in the other's code.
+    uint32_t fbase = 0, seq = 0;
+    if (wv >= clips_per_wg) {
+        // ------------------------------------------------------------------ packer: quantise, serialise, flush
+        // its clip slot waits for this wave (the transform wave has a third of a frame to spare): it goes first on its SIMD
+#ifndef FLO_PRIO_P
+#define FLO_PRIO_P 1
+#endif
+        __builtin_amdgcn_s_setprio(FLO_PRIO_P);
+        typedef __attribute__((address_space(3))) v4f lds_v4f;
+        float athn[16];
+        uint32_t ts_a[16];
+        {
+            const uint32_t ts0 = (uint32_t)(uintptr_t)cs.ts[0];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 a4 = A.T.pack[(kRowAthN + q) * 64 + lane];
+                const float4 b4 = A.T.pack[(kRowBoN + q) * 64 + lane];
+                athn[4 * q + 0] = a4.x, athn[4 * q + 1] = a4.y, athn[4 * q + 2] = a4.z, athn[4 * q + 3] = a4.w;
+                ts_a[4 * q + 0] = ts0 + __float_as_uint(b4.x), ts_a[4 * q + 1] = ts0 + __float_as_uint(b4.y);
+                ts_a[4 * q + 2] = ts0 + __float_as_uint(b4.z), ts_a[4 * q + 3] = ts0 + __float_as_uint(b4.w);
+            }
+        }
+        const uint32_t *const blk_g = reinterpret_cast<const uint32_t *>(A.T.pack + kRowBlk * 64);
+        // the lane's 16 bytes of block k of the coefficient buffer: element 144 k + 2 lane + 2 (lane >> 3)
+        const uint32_t cf_a = (uint32_t)(uintptr_t)cs.u.coef2 + 16u * (uint32_t)lane + 16u * ((uint32_t)lane >> 3);
+        uint8_t *const stage = cs.stage;
+        const uint32_t tab_a = (uint32_t)(uintptr_t)cs.packtab;
+        v4f cf[8];
+        bool have = false;   // cf holds the next frame's coefficients (taken before the previous frame's flush)
+        for (;;) {
+            unsigned got = 0;
+            if (lane == 0) got = atomicAdd(A.next_clip, 1u);
+            const unsigned clip = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+            if (lane == 0) cs.clip_cur = clip;
+            set_counter(&cs.clip_seq, ++seq);
+            if (clip >= (unsigned)A.n_clips) return;
+            const unsigned hops = A.clip_hops[clip];
+            const unsigned long long frame0 = A.clip_frame0[clip];
+            uint8_t *gout = A.out + A.out_off[clip];
+            unsigned long long written = 0;
+            uint32_t pend = 0, tailb = 0;
+#ifdef FLO_STAMPS
+            unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+            for (unsigned h = 0; h < hops; h++) {
+                const int ln = lane_id_opaque();
+                const uint32_t g = fbase + h;
+                if (!have) {
+                    wait_counter(&cs.coef_ready, g + 1);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) cf[k] = *reinterpret_cast<const lds_v4f *>((uintptr_t)(cf_a + 1152u * (uint32_t)k));
+                    set_counter(&cs.consumed, g + 1);   // (behind the reads: a wave's LDS instructions execute in order)
+                }
+                STAMP(0);
+#ifdef FLO_STAMPS
+                const unsigned long long st_frame0 = st_last;
+#endif
+                wait_counter(&cs.ts_ready, g + 1);
+                STAMP(5);
+                const uint32_t par = g & 1u;
+                const uint32_t sfw_both = cs.sfwh[par][ln >> 5][ln & 31];   // scale words: lanes 0..24 left, 32..56 right
+                // bands present in each block of 128 positions: eight scalars fetched per frame (one s_load, answered by the
+                // scalar cache while this wave waits for its partner) rather than held across the packer's scalar-heavy code
+                uint32_t blk[8];
+                {
+                    const uint32_t *bp = blk_g;
+                    asm volatile("" : "+s"(bp));
+#pragma unroll
+                    for (int q = 0; q < 8; q++) blk[q] = bp[q];
+                }
+                const uint32_t alive = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cs.alive[par][0] | cs.alive[par][1]));
+                uint32_t xd[2][8];   // xd[ch][k] = positions 128 k + 2 lane (low half) and + 1
+                if (par) quantise_nat<512>(cf, ts_a, athn, alive, blk, xd);
+                else quantise_nat<0>(cf, ts_a, athn, alive, blk, xd);
+                STAMP(1);
+                if (DBG && A.dbg_q) {
+#pragma unroll
+                    for (int ch = 0; ch < 2; ch++) {
+                        uint32_t *dq = reinterpret_cast<uint32_t *>(A.dbg_q + ((frame0 + h) * 2 + ch) * 1024);
+#pragma unroll
+                        for (int k = 0; k < 8; k++) dq[64 * k + ln] = xd[ch][k];
+                    }
+                }
+                // the < 16 bytes the previous frame left unflushed go back to the front of the staging buffer
+                if (ln < (int)pend) stage[ln] = (uint8_t)tailb;
+                uint8_t *f = stage + pend;
+                const uint32_t f_a = (uint32_t)(uintptr_t)f;
+                if ((ln & 31) < 25) {
+                    uint8_t *p = f + 12 + 50 * (ln >> 5) + 2 * (ln & 31);
+                    lds_st8<0>(p, sfw_both);
+                    lds_st8<1>(p, sfw_both >> 8);
+                }
+                uint32_t tot[2];
+                uint32_t pos = 112;   // 12 + 50 * 2: length word of channel 0
+                // each channel's blob: the item form (up to 128 non-zeros), else the block form, else - a dense frame with many
+                // runs or a run longer than 255, q >= 0.99 in practice - the general form; same bytes (tests compare them)
+#pragma unroll
+                for (int ch = 0; ch < 2; ch++) {
+                    uint32_t t = sparse_item_pack(ln, xd[ch], f_a + pos + 4u, tab_a);
+                    if (t == kSparseFallback) t = sparse_block_pack(ln, xd[ch], f_a + pos + 4u, tab_a);
+                    if (t == kSparseFallback) {   // uniform: dense frame (many runs, a run longer than 255)
+                        // the general form wants the lane's 16 contiguous values: one trip through the (still unused) tail of
+                        // the staging buffer re-deals the dwords
+                        uint32_t *scr = reinterpret_cast<uint32_t *>(stage + 2560);
+#pragma unroll
+                        for (int k = 0; k < 8; k++) scr[64 * k + ln] = xd[ch][k];
+                        wave_sync();
+                        const uint4 x0 = reinterpret_cast<const uint4 *>(scr)[2 * ln], x1 = reinterpret_cast<const uint4 *>(scr)[2 * ln + 1];
+                        wave_sync();
+                        const uint32_t xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        int q[1][16];
+                        uint32_t hi[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            hi[k] = xs[k] >> 16;
+                            q[0][2 * k] = (int)xs[k];
+                            q[0][2 * k + 1] = (int)hi[k];
+                        }
+                        SparsePlan P[1];
+                        sparse_plan_m(ln, nonzero_mask16_packed(xs, hi), P[0]);
+                        uint8_t *const dsts[1] = {f + pos + 4};
+                        // trash bytes of the general form: the tail of the staging buffer, two per lane
+                        const uint32_t trash[1] = {(uint32_t)((stage + kFrameCap + 64 + 2 * ln) - dsts[0])};
+                        sparse_emit_n<1>(ln, q, P, dsts, trash);
+                        t = P[0].total;
+                    }
+                    tot[ch] = t;
+                    pos += 4u + t;
+                    STAMP(2 + ch);
+                }
+                const uint32_t flen = pos, blob_len = flen - 10;
+                {
+                    // the 12 header bytes [253][frame_samples = 1024 u32][0][blob_len u32][BlockSize::Long = 0][2 channels] and the
+                    // two channel length words as ONE byte store: lane i < 12 holds header byte i, lanes 12..15 / 16..19 the bytes
+                    // of the first / second length word
+                    const uint32_t i = (uint32_t)ln;
+                    const uint32_t w0 = 0x000400FDu, w1 = blob_len << 16, w2 = (blob_len >> 16) | 0x02000000u;
+                    uint32_t wv4 = i < 4u ? w0 : (i < 8u ? w1 : w2);
+                    wv4 = i < 12u ? wv4 : (i < 16u ? tot[0] : tot[1]);
+                    const uint32_t off = i < 12u ? i : (i < 16u ? 112u - 12u + i : 116u - 16u + tot[0] + i);
+                    const uint32_t bv = wv4 >> (8u * (i & 3u));
+                    if (i < 20u) lds_st8<0>(f + off, bv);
+                    if (ln == 0) A.frame_size[frame0 + h] = flen;
+                }
+                wave_sync();
+                // the next frame's coefficients, if the transform wave already has them: taken in front of the flush, so
+                // that it has its buffer back a flush earlier and the reads are answered while the stores go out
+                have = (uint32_t)__builtin_amdgcn_readfirstlane((int)peek_counter(&cs.coef_ready)) >= g + 2;
+                if (have) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) cf[k] = *reinterpret_cast<const lds_v4f *>((uintptr_t)(cf_a + 1152u * (uint32_t)k));
+                    set_counter(&cs.consumed, g + 2);
+                }
+                const uint32_t haveb = pend + flen;
+                const uint32_t n16 = haveb >> 4;
+                const uint4 *src = reinterpret_cast<const uint4 *>(stage);
+                uint4 *dst = reinterpret_cast<uint4 *>(gout + written);
+                for (uint32_t i = ln; i < n16; i += 64) dst[i] = src[i];
+                pend = haveb & 15u;
+                tailb = (ln < (int)pend) ? stage[(n16 << 4) + ln] : 0u;
+                written += (unsigned long long)n16 << 4;
+                wave_sync();
+                STAMP(4);
+#ifdef FLO_STAMPS
+                {
+                    const unsigned long long busy = st_last - st_frame0;
+                    if (busy > 12000) { st_sum[9] += busy; st_sum[10] += 1; }
+                    if (busy > 20000) { st_sum[11] += busy; st_sum[12] += 1; }
+                }
+#endif
+            }
+            if (lane < (int)pend) gout[written + lane] = (uint8_t)tailb;
+            if (lane == 0) A.clip_bytes[clip] = written + pend;
+#ifdef FLO_STAMPS
+            if (A.dbg_stamps && lane == 0) {
+                st_sum[13] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+                             ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32) | ((unsigned long long)cl << 40);
+                for (int i = 0; i < 14; i++) A.dbg_stamps[((unsigned long long)clip * 2 + 1) * 16 + i] = st_sum[i];
+            }
+#endif
+            fbase += hops;
+        }
+    }
+
+    // ---------------------------------------------------------------------- transform wave: both channels
+#ifdef FLO_PRIO_T
+    __builtin_amdgcn_s_setprio(FLO_PRIO_T);
+#endif
+    LossyDevTables T = A.T;
+    T.pack = reinterpret_cast<const float4 *>(lds_raw);
+    for (;;) {
+        wait_counter(&cs.clip_seq, ++seq);
+        const unsigned clip = (unsigned)__builtin_amdgcn_readfirstlane((int)cs.clip_cur);
+        if (clip >= (unsigned)A.n_clips) return;
+        const unsigned hops = A.clip_hops[clip];
+        const unsigned long long frame0 = A.clip_frame0[clip];
+        const float *pcm = A.pcm + A.clip_off[clip];
+
+        float prev = 0.f;   // temporal masking state: channel 0's band b on lane b, channel 1's on lane 32 + b
+        v2f ae[8], ao[8], be[8], bo[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) ae[r] = ao[r] = splat2(0.f);  // pre-roll: 1024 zeros (encoder.rs:177)
+        if (!COEFFS) load_half_fast_2(lane_id_opaque(), pcm, 0, be, bo);   // (opaque: keeps 16 address pairs out of loop-invariant registers)
+#ifdef FLO_STAMPS
+        unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+        auto frame_body = [&](const unsigned h, v2f (&pe)[8], v2f (&po)[8], v2f (&ce)[8], v2f (&co)[8]) __attribute__((always_inline)) {
+            const int ln = lane_id_opaque();
+            const uint32_t g = fbase + h;
+            FLO_MARK("frame_begin");
+            // has the packer taken the previous frame's coefficients out of the buffer? (asked now, needed at the first exchange)
+            const uint32_t consumed_early = peek_counter(&cs.consumed);
+            v2f c[16];
+            if (COEFFS) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float4 v0 = reinterpret_cast<const float4 *>(A.in_coeffs + ((frame0 + h) * 2 + 0) * 1024 + 16 * ln)[q];
+                    const float4 v1 = reinterpret_cast<const float4 *>(A.in_coeffs + ((frame0 + h) * 2 + 1) * 1024 + 16 * ln)[q];
+                    c[4 * q] = (v2f){v0.x, v1.x}; c[4 * q + 1] = (v2f){v0.y, v1.y};
+                    c[4 * q + 2] = (v2f){v0.z, v1.z}; c[4 * q + 3] = (v2f){v0.w, v1.w};
+                }
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)consumed_early) < g) wait_counter(&cs.consumed, g);
+                float4 *p = reinterpret_cast<float4 *>(&cs.u.coef2[18 * ln]);   // where post_rotate_transpose_2 leaves them
+#pragma unroll
+                for (int q = 0; q < 8; q++) p[q] = make_float4(c[2 * q].x, c[2 * q].y, c[2 * q + 1].x, c[2 * q + 1].y);
+                wave_sync();
+            } else {
+                v2f zr[8], zi[8];
+                fold_2(ln, pe, po, ce, co, zr, zi, T);
+                FLO_MARK("fold_done");
+                STAMP(0);
+                // the older half is dead after the fold: the half-frame after next is loaded into its registers now and
+                // consumed at the top of the next call (see lossy_chain_kernel)
+                load_half_fast_2(ln, pcm, (long long)(h + 1) * 1024, pe, po);
+                FLO_MARK("prefetch_done");
+                STAMP(1);
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)consumed_early) < g) wait_counter(&cs.consumed, g);
+                STAMP(7);
+                fft512_2(ln, zr, zi, cs.u.xch4, T);
+                FLO_MARK("fft_done");
+                STAMP(2);
+                post_rotate_transpose_2(ln, zr, zi, cs.u.coef2, c, T);
+                FLO_MARK("postrot_done");
+                STAMP(3);
+                if (DBG && A.dbg_coeffs) {
+#pragma unroll
+                    for (int ch = 0; ch < 2; ch++) {
+                        float *d = A.dbg_coeffs + ((frame0 + h) * 2 + ch) * 1024 + 16 * ln;
+#pragma unroll
+                        for (int e = 0; e < 16; e++) d[e] = ch ? c[e].y : c[e].x;
+                    }
+                }
+            }
+            set_counter(&cs.coef_ready, g + 1);
+            // band statistics, masking level, temporal masking, scale factors (both channels)
+            float energy1, bmax1;   // channel 0's band b on lane b, channel 1's on lane 32 + b
+            band_stats_2<DIRTY>(ln, c, cs.slot, T, energy1, bmax1);
+            FLO_MARK("bandstats_done");
+            STAMP(4);
+            const int bnd = ln & 31, up = ln >> 5;
+            const float rcount = T.pack[kRowLane * 64 + ln].z;   // (the row holds band (lane & 31)'s value on every lane)
+            {
+                const float a = spread_threshold_2(ln, energy1, rcount, T);
+                const float sl = max_raw(a, prev * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
+                prev = sl;
+                const float tl1 = masking_amplitude(sl, T.smr_thr);
+                const float bm = bmax1;
+                const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
+                const uint32_t sfw1 = sf_word(sfv1);
+                if (bnd < 25) {
+                    typedef __attribute__((address_space(3))) float lds_f32;
+                    const uint32_t ts_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)cs.ts[g & 1u]);
+                    lds_f32 *tp = reinterpret_cast<lds_f32 *>((uintptr_t)(ts_s + 16u * (uint32_t)bnd + 4u * (uint32_t)up));
+                    tp[0] = tl1;
+                    tp[2] = sfv1;
+                    cs.sfwh[g & 1u][up][bnd] = (uint16_t)sfw1;
+                }
+                {   // bands with anything above their masking amplitude: channel 0's on bits 0..24, channel 1's on bits 32..56
+                    const unsigned long long al = __ballot(bnd < 25 && bm > tl1);
+                    if (ln == 0) {
+                        cs.alive[g & 1u][0] = (uint32_t)al;
+                        cs.alive[g & 1u][1] = (uint32_t)(al >> 32);
+                    }
+                }
+                if (DBG && A.dbg_sfw && bnd < 25) A.dbg_sfw[((frame0 + h) * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
+            }
+            set_counter(&cs.ts_ready, g + 1);
+            FLO_MARK("frame_end");
+            STAMP(5);
+        };
+        for (unsigned h = 0; h < hops; h += 2) {
+            frame_body(h, ae, ao, be, bo);
+            if (h + 1 < hops) frame_body(h + 1, be, bo, ae, ao);
+        }
+#ifdef FLO_STAMPS
+        if (A.dbg_stamps && lane == 0) {   // [13]: where the wave ran (HW_ID, XCC_ID, clip slot): diag/stamps_clips.py groups the records by it
+            st_sum[13] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
+                         ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32) | ((unsigned long long)cl << 40);
+            for (int i = 0; i < 14; i++) A.dbg_stamps[((unsigned long long)clip * 2) * 16 + i] = st_sum[i];
+        }
+#endif
+        fbase += hops;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- frame-parallel
@@ -1220,7 +1586,7 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
         }
     }
     float energy1, bmax1;   // channel 0's band b on lane b, channel 1's on lane 32 + b
-    band_stats_2(lane, c, lds, T, energy1, bmax1);
+    band_stats_2(lane, c, lds.u.a.slot, T, energy1, bmax1);
     const int bnd = lane & 31, up = lane >> 5;
     const float rcount = T.pack[kRowLane * 64 + bnd].z;
     const float a = spread_threshold_2(lane, energy1, rcount, T);
@@ -1531,23 +1897,25 @@ __global__ __launch_bounds__(64) void mdct_only_kernel(LossyDevTables T, const f
     for (int q = 0; q < 4; q++) d[q] = make_float4(c[0][4 * q], c[0][4 * q + 1], c[0][4 * q + 2], c[0][4 * q + 3]);
 }
 
-// serialize_sparse of independent 1024-value vectors into fixed slots (flo_sparse_pack): the packer wave's own
-// routine, i.e. the block form with the general form behind it for the vectors it declines. form = 1 forces the
-// general form for every vector (tests compare the two).
+// serialize_sparse of independent 1024-value vectors into fixed slots (flo_sparse_pack). form 0: the packer wave's own
+// routine - the item form, behind it the block form for vectors with more than 128 non-zeros, behind that the general
+// form for the vectors the block form declines; form 2 starts at the block form, form 1 forces the general form for
+// every vector (tests compare the three).
 __global__ __launch_bounds__(64) void sparse_only_kernel(const short *q, unsigned long long n, uint8_t *slots,
                                                          uint32_t *sizes, int form) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[2080 + 128];
-    __shared__ uint32_t runtab[kRunTabEntries];
+    __shared__ uint32_t runtab[kPackTabDwords];
     const unsigned long long w = blockIdx.x;
     if (w >= n) return;
     const int lane = lane_id();
     const unsigned short *qv = reinterpret_cast<const unsigned short *>(q) + w * 1024;
     uint32_t total = kSparseFallback;
-    if (form == 0) {
+    if (form == 0 || form == 2) {
         uint32_t xd[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) xd[k] = reinterpret_cast<const uint32_t *>(qv)[64 * k + lane];
-        total = sparse_block_pack(lane, xd, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab);
+        if (form == 0) total = sparse_item_pack(lane, xd, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab);
+        if (total == kSparseFallback) total = sparse_block_pack(lane, xd, (uint32_t)(uintptr_t)stage, (uint32_t)(uintptr_t)runtab);
     }
     if (total == kSparseFallback) {
         int v[16];
@@ -1711,6 +2079,35 @@ static int launch_chain2x_t(const LossyArgs &A, hipStream_t s) {
     hipLaunchKernelGGL((lossy_chain2x_kernel<COEFFS, DIRTY, DBG>), dim3(wgs), dim3(128 * g), lds, s, A, g);
     FLO_LAUNCH_CHECK();
     return 0;
+}
+// clips per workgroup of the two-wave form whose packer quantises
+int chain2q_clips_per_wg(int n_clips) {
+    int g = (n_clips + 255) / 256;
+    const int gmax = (int)((160 * 1024 - kPackBytesHotT) / sizeof(Clip2qLds));
+    if (g > gmax) g = gmax;
+    if (g > FLO_C2X_THREADS / 128) g = FLO_C2X_THREADS / 128;   // twelve waves: three per SIMD (up to 168 registers each)
+    return g < 1 ? 1 : g;
+}
+template <bool COEFFS, uint32_t DIRTY, bool DBG>
+static int launch_chain2q_t(const LossyArgs &A, hipStream_t s) {
+    int g = chain2q_clips_per_wg(A.n_clips);
+    if (const char *e = getenv("FLO_CHAIN2X_CLIPS")) {   // diagnostic: clips per workgroup
+        const int v = atoi(e);
+        if (v >= 1 && v <= FLO_C2X_THREADS / 128) g = v;
+    }
+    const size_t lds = kPackBytesHotT + (size_t)g * sizeof(Clip2qLds);
+    if (int rc = allow_big_lds(reinterpret_cast<const void *>(&lossy_chain2q_kernel<COEFFS, DIRTY, DBG>))) return rc;
+    unsigned wgs = (unsigned)((A.n_clips + g - 1) / g);
+    if (A.n_cus > 0 && wgs > (unsigned)A.n_cus) wgs = (unsigned)A.n_cus;   // persistent: one workgroup per CU, clips dealt dynamically
+    hipLaunchKernelGGL((lossy_chain2q_kernel<COEFFS, DIRTY, DBG>), dim3(wgs), dim3(128 * g), lds, s, A, g);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_lossy_chain2q(const LossyArgs &A, hipStream_t s) {
+    if (A.nch != 2 || A.exact) return -1;   // the exact-threshold test yardstick lives in the other forms
+    if (A.in_coeffs) return launch_chain2q_t<true, 0xFFFFu, true>(A, s);
+    if (A.dbg_coeffs || A.dbg_q || A.dbg_sfw) return launch_chain2q_t<false, 0xFFFFu, true>(A, s);
+    return (A.T.dirty | 0x8000u) == kDirty44k ? launch_chain2q_t<false, kDirty44k, false>(A, s) : launch_chain2q_t<false, 0xFFFFu, false>(A, s);
 }
 int launch_lossy_chain2x(const LossyArgs &A, hipStream_t s) {
     if (A.nch != 2 || A.exact) return -1;   // the exact-threshold test yardstick lives in the other forms

@@ -143,8 +143,16 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
             P(kRowF2 + idx / 4, lane, idx % 4 + 1) = t.t2[((k - 1) * 8 + (lane & 7)) * 2 + 1];
         }
         for (int e = 0; e < 16; e++) P(kRowAth + e / 4, lane, e % 4) = t.ath_lin[16 * lane + e];
+        // the same thresholds in the packer wave's natural layout: entry 2 k + j = position 128 k + 2 lane + j
+        for (int e = 0; e < 16; e++) P(kRowAthN + e / 4, lane, e % 4) = t.ath_lin[128 * (e >> 1) + 2 * lane + (e & 1)];
     }
 
+    // bands present in each block of 128 positions (the packer wave skips blocks none of whose bands can keep anything)
+    for (int k = 0; k < 8; k++) {
+        uint32_t m = 0;
+        for (int i = 0; i < 128; i++) m |= 1u << t.band[128 * k + i];
+        memcpy(&t.pack[((size_t)kRowBlk * 64) * 4 + k], &m, 4);
+    }
     // segments of the contiguous layout (lane j owns k in [16j, 16j+16))
     t.lane_bnd.assign(64, 0);
     t.lane_slot0.assign(64, 0);
@@ -212,6 +220,7 @@ void build_lossy_tables(uint32_t sample_rate, float quality, LossyTablesHost &t)
             const uint32_t v = (sidx < bs1 ? sidx : (uint32_t)(kSlotCapHost + 64)) * 8u;
             memcpy(&t.pack_ext[((size_t)((u - 24) / 4) * 64 + lane) * 4 + u % 4], &v, 4);
         }
+        for (int e = 0; e < 16; e++) PU(kRowBoN + e / 4, lane, e % 4, (uint32_t)t.band[128 * (e >> 1) + 2 * lane + (e & 1)] * 16u);
         PU(kRowLane, lane, 0, t.lane_bnd[lane]);
         PU(kRowLane, lane, 1, t.lane_slot0[lane]);
         PU(kRowLane, lane, 2, rc);

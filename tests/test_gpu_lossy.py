@@ -55,9 +55,10 @@ def _patterns():
     return np.array(pats)
 
 
-@pytest.mark.parametrize("form", [0, 1], ids=["encoder", "general"])
+@pytest.mark.parametrize("form", [0, 1, 2], ids=["encoder", "general", "block"])
 def test_sparse_pack_bit_exact(ctx, form):
-    # form 0 = the packer as every encode runs it (block form, the general form behind it for dense vectors)
+    # form 0 = the packer as every encode runs it (item form up to 128 non-zeros, block form behind it, the general form
+    # behind that for dense vectors); form 2 starts at the block form
     pats = _patterns()
     got = ctx.sparse_pack(pats, form)
     for i, p in enumerate(pats):
@@ -112,12 +113,32 @@ def test_sparse_pack_block_form_on_structured_vectors(ctx):
     for k in (64, 128, 192):
         a = np.zeros(1024, np.int16); a[:k] = 3; a[k + 200:k + 203] = 4; pats.append(a)      # wide record starts item k
         b = np.zeros(1024, np.int16); b[:k - 1] = 3; b[k + 200:k + 203] = 4; pats.append(b)
+    # what the item form has to get right: 0 / 1 / 63 / 64 / 65 / 127 / 128 / 129 non-zeros (one and two items per lane, the
+    # hand-over to the block form), records that start or end on item 63 / 64, zero runs of 127 / 128 / 129 in front of
+    # the first item, between items and behind the last, a first item at position 0, a last one at 1023
+    for n in (0, 1, 2, 63, 64, 65, 66, 126, 127, 128, 129, 130):
+        for stride in (1, 2, 3, 7):
+            a = np.zeros(1024, np.int16); a[np.arange(n) * stride] = rng.integers(1, 32767, n) * rng.choice([-1, 1], n); pats.append(a)
+            b = np.zeros(1024, np.int16); b[1023 - np.arange(n) * stride] = -5; pats.append(b)
+        for lead in (1, 126, 127, 128, 129, 130, 255, 256, 700):
+            a = np.zeros(1024, np.int16); a[lead:lead + n] = 6; pats.append(a)                      # one run behind a lead of zeros
+            b = np.zeros(1024, np.int16); b[:n // 2] = 6; b[n // 2 + lead:n // 2 + lead + (n - n // 2)] = -6; pats.append(b)
+    for first_run in (62, 63, 64, 65):
+        for gap in (1, 2, 127, 128, 129):
+            for second in (1, 2, 30, 63, 64):
+                a = np.zeros(1024, np.int16); a[3:3 + first_run] = 9; a[3 + first_run + gap:3 + first_run + gap + second] = -9; pats.append(a)
+    for _ in range(200):
+        n = int(rng.integers(0, 140))
+        a = np.zeros(1024, np.int16)
+        a[rng.choice(1024, n, replace=False)] = rng.integers(-32768, 32768, n)
+        pats.append(a)
     pats = np.array(pats)
-    got0, got1 = ctx.sparse_pack(pats, 0), ctx.sparse_pack(pats, 1)
+    got0, got1, got2 = ctx.sparse_pack(pats, 0), ctx.sparse_pack(pats, 1), ctx.sparse_pack(pats, 2)
     for i, p in enumerate(pats):
         ref = O.serialize_sparse(p)
         assert got0[i] == ref, i
         assert got1[i] == ref, i
+        assert got2[i] == ref, i
 
 
 @pytest.mark.parametrize("exact", [False, True], ids=["shipped", "exact"])
@@ -129,14 +150,17 @@ def test_quantiser_fed_oracle_spectra(ctx, q, exact):
     # "exact" adds the reference's dB-domain re-check next to the threshold. Both meet the same bound.
     pcm = signals.music_like(44100, 30000, 2, seed=3)
     o = O.lossy_analyze(pcm, 44100, 2, q)
-    g = ctx.lossy_quantize(o["coeffs"], 44100, q, exact=exact)
-    flips = ((g["q"] != 0) != (o["q"] != 0)).mean()
-    mism = (g["q"] != o["q"]).mean()
-    print(f"q={q} exact={exact}: keep/drop flip rate {flips:.2e}, integer mismatch rate {mism:.2e}")
-    assert flips <= 1e-4, flips    # SURVEY 8c(ii) allows 5e-4; the band-energy summation order is the only difference
-    assert mism <= 1e-4, mism
-    assert np.abs(g["sf_words"].astype(int) - o["sf_words"].astype(int)).max() <= 1
-    assert (g["sf_words"] != o["sf_words"]).mean() <= 1e-3
+    for path in ((0,) if exact else (0, 4, 5)):   # 5 = the benchmarked form: the quantiser runs in the packer wave, natural layout
+        ctx.force_path(path)
+        g = ctx.lossy_quantize(o["coeffs"], 44100, q, exact=exact)
+        ctx.force_path(0)
+        flips = ((g["q"] != 0) != (o["q"] != 0)).mean()
+        mism = (g["q"] != o["q"]).mean()
+        print(f"q={q} exact={exact} path={path}: keep/drop flip rate {flips:.2e}, integer mismatch rate {mism:.2e}")
+        assert flips <= 1e-4, flips    # SURVEY 8c(ii) allows 5e-4; the band-energy summation order is the only difference
+        assert mism <= 1e-4, mism
+        assert np.abs(g["sf_words"].astype(int) - o["sf_words"].astype(int)).max() <= 1
+        assert (g["sf_words"] != o["sf_words"]).mean() <= 1e-3
 
 
 def test_shipped_quantiser_on_a_long_clip_reports_its_flip_rate(ctx):
@@ -144,7 +168,9 @@ def test_shipped_quantiser_on_a_long_clip_reports_its_flip_rate(ctx):
     # production instantiation only: the measured keep/drop flip rate against the oracle's decisions
     pcm = O.synth_clip(441000, 2, 0xF10A0D10, 7)
     o = O.lossy_analyze(pcm, 44100, 2, 0.55)
+    ctx.force_path(5)          # the benchmarked form
     g = ctx.lossy_quantize(o["coeffs"], 44100, 0.55, exact=False)
+    ctx.force_path(0)
     flips = int(((g["q"] != 0) != (o["q"] != 0)).sum())
     print(f"shipped quantiser, 10 s synthetic clip: {flips} keep/drop flips in {o['q'].size} coefficients ({flips / o['q'].size:.2e})")
     assert flips <= 1e-4 * o["q"].size
@@ -189,7 +215,7 @@ def test_analyze_parity(ctx, ch, q):
     pcm = signals.music_like(44100, 40000, ch, seed=10 + ch)
     o = O.lossy_analyze(pcm, 44100, ch, q)
     first = None
-    for path in (1, 2, 3, 4):      # 3 and 4 are stereo forms (mono falls back to 1)
+    for path in (1, 2, 3, 4, 5):      # 3, 4 and 5 are stereo forms (mono falls back to 1)
         ctx.force_path(path)
         g = ctx.lossy_analyze(pcm, 44100, ch, q)
         compare_lossy_stage(g, o, 44100, tag=f"path{path}")
@@ -207,8 +233,9 @@ def test_other_sample_rates(ctx, sr):
     pcm = signals.music_like(sr, 20000, 2, seed=sr)
     o = O.lossy_analyze(pcm, sr, 2, 0.55)
     compare_lossy_stage(ctx.lossy_analyze(pcm, sr, 2, 0.55), o, sr)
-    ctx.force_path(4)          # the lock-step stereo form has its own band-statistics code: other band tables too
-    compare_lossy_stage(ctx.lossy_analyze(pcm, sr, 2, 0.55), o, sr, tag="path4")
+    for path in (4, 5):        # the lock-step stereo forms have their own band-statistics code (5: and the quantiser in the packer wave, natural layout): other band tables too
+        ctx.force_path(path)
+        compare_lossy_stage(ctx.lossy_analyze(pcm, sr, 2, 0.55), o, sr, tag=f"path{path}")
     ctx.force_path(0)
     # the whole drop-in call and the decode at this rate (from 128 kHz up band 24 spans more than 48 lane segments)
     flo = ctx.encode_lossy(pcm, sr, 2, 0.55)
@@ -229,10 +256,13 @@ def test_chain_and_frame_parallel_forms_give_identical_files(ctx):
     c = ctx.encode_lossy(pcm, 44100, 2, 0.55)
     ctx.force_path(4)
     d = ctx.encode_lossy(pcm, 44100, 2, 0.55)
+    ctx.force_path(5)
+    e = ctx.encode_lossy(pcm, 44100, 2, 0.55)
     ctx.force_path(0)
     assert a == b
     assert a == c
     assert a == d
+    assert a == e
 
 
 @pytest.mark.parametrize("q", [0.0, 0.55, 1.0])
@@ -247,9 +277,12 @@ def test_three_wave_pipeline_matches_chain_on_a_ragged_batch(ctx, q):
     b = ctx.encode_batch(1, clips, 44100, 2, q)
     ctx.force_path(4)     # lock-step stereo transform wave, persistent workgroups dealing the clips dynamically
     c = ctx.encode_batch(1, clips, 44100, 2, q)
+    ctx.force_path(5)     # the same pair of waves, the quantiser in the packer wave
+    d = ctx.encode_batch(1, clips, 44100, 2, q)
     ctx.force_path(0)
     assert a == b
     assert a == c
+    assert a == d
 
 
 @pytest.mark.parametrize("ch", [1, 2])
@@ -298,7 +331,7 @@ def test_near_goldens_reference_made_files(ctx, name, q, src):
 def test_edge_lengths(ctx, n, ch):
     pcm = signals.fast_noise(n * ch, 7, 0.4)
     o = O.encode_lossy(pcm, 44100, ch, 0.55)
-    for path in (0, 1, 2, 3, 4):     # 0 = what an encode call picks by itself, 4 = the benchmarked lock-step form
+    for path in (0, 1, 2, 3, 4, 5):     # 0 = what an encode call picks by itself, 5 = the benchmarked lock-step form
         ctx.force_path(path)
         g = ctx.encode_lossy(pcm, 44100, ch, 0.55)
         fg, _ = same_structure(g, o)
@@ -516,7 +549,7 @@ def test_kernel_forms_agree_on_loud_and_lopsided_stereo(ctx, amp):
             x[::2] = 0.0
         clips.append(x.astype(np.float32))
     outs = {}
-    for form in (4, 1, 2, 3):
+    for form in (4, 1, 2, 3, 5):
         b = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [c.size for c in clips], sr, ch, 0.55)
         for i, c in enumerate(clips):
             b.upload(i, c)
@@ -524,5 +557,5 @@ def test_kernel_forms_agree_on_loud_and_lopsided_stereo(ctx, amp):
         b.sync()
         outs[form] = [b.fetch(i) for i in range(len(clips))]
         b.close()
-    for form in (1, 2, 3):
+    for form in (1, 2, 3, 5):
         assert outs[form] == outs[4], form
