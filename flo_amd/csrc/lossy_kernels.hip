@@ -1220,6 +1220,26 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
             for (unsigned h = 0; h < hops; h++) {
                 const int ln = lane_id_opaque();
                 const uint32_t g = fbase + h;
+                // The next frame's coefficients are taken as soon as the transform wave has them and this wave's registers
+                // are free (behind the quantiser, between the channels' blobs, in front of the flush): the sooner the
+                // transform wave has its buffer back, the less it waits in front of its next FFT exchange.
+                auto take_next = [&]() __attribute__((always_inline)) {
+                    if (!have && (uint32_t)__builtin_amdgcn_readfirstlane((int)peek_counter(&cs.coef_ready)) >= g + 2) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) cf[k] = *reinterpret_cast<const lds_v4f *>((uintptr_t)(cf_a + 1152u * (uint32_t)k));
+                        set_counter(&cs.consumed, g + 2);
+                        have = true;
+                    }
+                };
+                // bands present in each block of 128 positions: eight scalars fetched per frame (one s_load, answered by the
+                // scalar cache while this wave waits for its partner) rather than held across the packer's scalar-heavy code
+                uint32_t blk[8];
+                {
+                    const uint32_t *bp = blk_g;
+                    asm volatile("" : "+s"(bp));
+#pragma unroll
+                    for (int q = 0; q < 8; q++) blk[q] = bp[q];
+                }
                 if (!have) {
                     wait_counter(&cs.coef_ready, g + 1);
 #pragma unroll
@@ -1234,19 +1254,12 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
                 STAMP(5);
                 const uint32_t par = g & 1u;
                 const uint32_t sfw_both = cs.sfwh[par][ln >> 5][ln & 31];   // scale words: lanes 0..24 left, 32..56 right
-                // bands present in each block of 128 positions: eight scalars fetched per frame (one s_load, answered by the
-                // scalar cache while this wave waits for its partner) rather than held across the packer's scalar-heavy code
-                uint32_t blk[8];
-                {
-                    const uint32_t *bp = blk_g;
-                    asm volatile("" : "+s"(bp));
-#pragma unroll
-                    for (int q = 0; q < 8; q++) blk[q] = bp[q];
-                }
                 const uint32_t alive = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cs.alive[par][0] | cs.alive[par][1]));
                 uint32_t xd[2][8];   // xd[ch][k] = positions 128 k + 2 lane (low half) and + 1
                 if (par) quantise_nat<512>(cf, ts_a, athn, alive, blk, xd);
                 else quantise_nat<0>(cf, ts_a, athn, alive, blk, xd);
+                have = false;   // cf is free again
+                take_next();
                 STAMP(1);
                 if (DBG && A.dbg_q) {
 #pragma unroll
@@ -1301,6 +1314,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
                     }
                     tot[ch] = t;
                     pos += 4u + t;
+                    if (ch == 0) take_next();
                     STAMP(2 + ch);
                 }
                 const uint32_t flen = pos, blob_len = flen - 10;
@@ -1320,12 +1334,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
                 wave_sync();
                 // the next frame's coefficients, if the transform wave already has them: taken in front of the flush, so
                 // that it has its buffer back a flush earlier and the reads are answered while the stores go out
-                have = (uint32_t)__builtin_amdgcn_readfirstlane((int)peek_counter(&cs.coef_ready)) >= g + 2;
-                if (have) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) cf[k] = *reinterpret_cast<const lds_v4f *>((uintptr_t)(cf_a + 1152u * (uint32_t)k));
-                    set_counter(&cs.consumed, g + 2);
-                }
+                take_next();
                 const uint32_t haveb = pend + flen;
                 const uint32_t n16 = haveb >> 4;
                 const uint4 *src = reinterpret_cast<const uint4 *>(stage);
@@ -1380,7 +1389,14 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
         unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
-        auto frame_body = [&](const unsigned h, v2f (&pe)[8], v2f (&po)[8], v2f (&ce)[8], v2f (&co)[8]) __attribute__((always_inline)) {
+        // The frame loop is software-pipelined by one phase: the masking pass of frame h - one long dependent chain on 50
+        // lanes (logarithm, DPP maxima, exponential, division) - and the fold of frame h + 1, which only needs PCM that is
+        // already in registers, sit in the same basic block, so the fold's packed arithmetic fills the issue slots the
+        // chain leaves empty. Entering frame h, (zr, zi) hold its folded input; `fh` is the half-frame the next fold
+        // takes first and `nh` the free register set the half after it is loaded into, at the TOP of the frame.
+        v2f zr[8], zi[8];
+        if (!COEFFS) fold_2(lane_id_opaque(), ae, ao, be, bo, zr, zi, T);
+        auto frame_body = [&](const unsigned h, v2f (&ne)[8], v2f (&no)[8], v2f (&fe)[8], v2f (&fo)[8]) __attribute__((always_inline)) {
             const int ln = lane_id_opaque();
             const uint32_t g = fbase + h;
             FLO_MARK("frame_begin");
@@ -1401,13 +1417,9 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
                 for (int q = 0; q < 8; q++) p[q] = make_float4(c[2 * q].x, c[2 * q].y, c[2 * q + 1].x, c[2 * q + 1].y);
                 wave_sync();
             } else {
-                v2f zr[8], zi[8];
-                fold_2(ln, pe, po, ce, co, zr, zi, T);
-                FLO_MARK("fold_done");
-                STAMP(0);
-                // the older half is dead after the fold: the half-frame after next is loaded into its registers now and
-                // consumed at the top of the next call (see lossy_chain_kernel)
-                load_half_fast_2(ln, pcm, (long long)(h + 1) * 1024, pe, po);
+                // the half-frame after next, into the registers the last fold freed; consumed at the end of this frame.
+                // Unconditional, also behind the last frame (the batch allocates one spare half-frame per clip)
+                load_half_fast_2(ln, pcm, (long long)(h + 1) * 1024, ne, no);
                 FLO_MARK("prefetch_done");
                 STAMP(1);
                 if ((uint32_t)__builtin_amdgcn_readfirstlane((int)consumed_early) < g) wait_counter(&cs.consumed, g);
@@ -1435,31 +1447,37 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
             STAMP(4);
             const int bnd = ln & 31, up = ln >> 5;
             const float rcount = T.pack[kRowLane * 64 + ln].z;   // (the row holds band (lane & 31)'s value on every lane)
-            {
-                const float a = spread_threshold_2(ln, energy1, rcount, T);
-                const float sl = max_raw(a, prev * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
-                prev = sl;
-                const float tl1 = masking_amplitude(sl, T.smr_thr);
-                const float bm = bmax1;
-                const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
-                const uint32_t sfw1 = sf_word(sfv1);
-                if (bnd < 25) {
-                    typedef __attribute__((address_space(3))) float lds_f32;
-                    const uint32_t ts_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)cs.ts[g & 1u]);
-                    lds_f32 *tp = reinterpret_cast<lds_f32 *>((uintptr_t)(ts_s + 16u * (uint32_t)bnd + 4u * (uint32_t)up));
-                    tp[0] = tl1;
-                    tp[2] = sfv1;
-                    cs.sfwh[g & 1u][up][bnd] = (uint16_t)sfw1;
-                }
-                {   // bands with anything above their masking amplitude: channel 0's on bits 0..24, channel 1's on bits 32..56
-                    const unsigned long long al = __ballot(bnd < 25 && bm > tl1);
-                    if (ln == 0) {
-                        cs.alive[g & 1u][0] = (uint32_t)al;
-                        cs.alive[g & 1u][1] = (uint32_t)(al >> 32);
-                    }
-                }
-                if (DBG && A.dbg_sfw && bnd < 25) A.dbg_sfw[((frame0 + h) * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
+            // the next frame's fold: independent of the masking pass below (no memory clobber between the two; in front of it
+            // in program order because the pass ends in a rarely taken branch that would fence the scheduler)
+            if (!COEFFS) fold_2(ln, fe, fo, ne, no, zr, zi, T);
+#if (FLO_SKIP & 16) == 0
+            const float a = spread_threshold_2(ln, energy1, rcount, T);
+            const float sl = max_raw(a, prev * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
+            prev = sl;
+            const float tl1 = masking_amplitude(sl, T.smr_thr);
+            const float bm = bmax1;
+            const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
+            const uint32_t sfw1 = sf_word(sfv1);
+#else   // diagnostic (results invalid): what the masking pass costs
+            const float bm = bmax1, tl1 = energy1 * 1e-3f + rcount, sfv1 = bm * 100.f + 1.f;
+            const uint32_t sfw1 = __float_as_uint(tl1) >> 16;
+#endif
+            // bands with anything above their masking amplitude: channel 0's on bits 0..24, channel 1's on bits 32..56
+            const unsigned long long al = __ballot(bnd < 25 && bm > tl1);
+            FLO_MARK("fold_done");
+            if (bnd < 25) {
+                typedef __attribute__((address_space(3))) float lds_f32;
+                const uint32_t ts_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)cs.ts[g & 1u]);
+                lds_f32 *tp = reinterpret_cast<lds_f32 *>((uintptr_t)(ts_s + 16u * (uint32_t)bnd + 4u * (uint32_t)up));
+                tp[0] = tl1;
+                tp[2] = sfv1;
+                cs.sfwh[g & 1u][up][bnd] = (uint16_t)sfw1;
             }
+            if (ln == 0) {
+                cs.alive[g & 1u][0] = (uint32_t)al;
+                cs.alive[g & 1u][1] = (uint32_t)(al >> 32);
+            }
+            if (DBG && A.dbg_sfw && bnd < 25) A.dbg_sfw[((frame0 + h) * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
             set_counter(&cs.ts_ready, g + 1);
             FLO_MARK("frame_end");
             STAMP(5);
