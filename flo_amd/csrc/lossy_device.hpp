@@ -551,8 +551,13 @@ __device__ __forceinline__ void cmul_2_pair(v2f &xr, v2f &xi, v2f w) {
     xi = i;
 }
 
-// fft512 for both channels; x4: kXch4 float4 elements (re0, re1, im0, im1), row stride kXchStride elements
-__device__ __forceinline__ void fft512_2(const int lane, v2f (&zr)[8], v2f (&zi)[8], float4 *x4, const LossyDevTables &T) {
+// fft512 for both channels; x4: kXch4 float4 elements (re0, re1, im0, im1), row stride kXchStride elements.
+// shadow(): code of the caller's that does not touch (zr, zi) nor wait for LDS, placed behind the issue of the first
+// exchange's reads: it runs while they are answered (a wave issues in order: what follows the reads in program order is what
+// fills their latency).
+struct NoShadow { __device__ __forceinline__ void operator()() const {} };
+template <typename F = NoShadow>
+__device__ __forceinline__ void fft512_2(const int lane, v2f (&zr)[8], v2f (&zi)[8], float4 *x4, const LossyDevTables &T, F &&shadow = F()) {
     dft8_2(zr, zi);
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
@@ -571,6 +576,7 @@ __device__ __forceinline__ void fft512_2(const int lane, v2f (&zr)[8], v2f (&zi)
             zr[r] = (v2f){v.x, v.y};
             zi[r] = (v2f){v.z, v.w};
         }
+        shadow();
         wave_sync();
     }
     dft8_2(zr, zi);
@@ -856,46 +862,77 @@ __device__ __forceinline__ float ror1(float x) {
 // 32..56 (band = lane & 31). Every lane goes through exactly the operations of spread_threshold; what differs is the
 // bookkeeping between the halves: the row-0 / row-2 lanes take bands 16..24 from lane 16 / 48, and the shifted copy of
 // channel 0's band 24 is kept from reaching channel 1's band 0 (it arrives at lane 32 after exactly eight shifts).
-__device__ __forceinline__ float spread_threshold_2(const int lane, float energy, float rcount, const LossyDevTables &T) {
-    const float4 sd0 = T.pack[kRowS10 * 64], sd1 = T.pack[kRowS10 * 64 + 1];
+// (sd0, sd1 = the first two float4 of row kRowS10, handed in: a caller that runs the pass in the shadow of other LDS traffic
+// fetches them ahead of it)
+__device__ __forceinline__ float spread_threshold_2r(const int lane, float energy, float rcount, const float4 sd0, const float4 sd1,
+                                                     const LossyDevTables &T) {
     const int b = lane & 31;
     const bool is_band = b < 25;
     float band_db = -100.0f;
     if (is_band && rcount > 0.f && energy > 1e-10f) band_db = 3.01029995663981195f * __builtin_amdgcn_logf(energy * rcount);
     if (!is_band) band_db = -__builtin_inff();
     const float ninf = -__builtin_inff();
-    float sm = band_db;
-    sm = max_self_dpp<0x101>(sm);
-    sm = max_self_dpp<0x102>(sm);
-    sm = max_self_dpp<0x104>(sm);
-    sm = max_self_dpp<0x108>(sm);
-    const float hi0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 16));
-    const float hi1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 48));
-    // bands 0..15 of either channel also see bands 16..24: two maxima with a scalar operand under the lanes' exec masks (a
-    // select between the two scalars first cost two moves, a compare, a select and a branch)
+    // Two chains over the bands of both channels, written out as one instruction sequence so that each fills the other's
+    // DPP wait states (a DPP operand may not be read within two instructions of its write; as separate helpers the
+    // chains cost an s_nop per step):
+    //   sm  = suffix maximum of band_db within each row of 16 lanes (row_shl 1, 2, 4, 8), then bands 0..15 of either
+    //         channel also take bands 16..24 (lane 16 / 48) by two maxima under exec masks;
+    //   acc = max over d = 1..8 of band_db[lane - d] + s10d[d]: the copies are ROTATED by one lane per step; what enters
+    //         lane 0 (channel 0's band 0) comes from lanes 63, 62, ..., idle lanes holding -inf, exactly like the lanes
+    //         31, 30, ... that feed channel 1's band 0 on lane 32. At the eighth step the values that started on lanes 24
+    //         and 56 (band 24 of either channel) would arrive: they are cut off one step earlier, on lanes 31 and 63.
+    // m = max(-100, sm, acc): the same set of maxima as the step-by-step form (no NaN can occur: band_db is a number or
+    // -inf, the s10d are finite), hence the same value.
+    float sm, cur, m, tt;
     {
+        float h0, h1;
         unsigned long long sv;
-        asm volatile("s_mov_b64 %0, exec\n\t"
-                     "s_mov_b64 exec, 0xffff\n\t"
-                     "v_max_f32 %1, %2, %1\n\t"
-                     "s_mov_b64 exec, %4\n\t"
-                     "v_max_f32 %1, %3, %1\n\t"
-                     "s_mov_b64 exec, %0"
-                     : "=&s"(sv), "+v"(sm)
-                     : "s"(hi0), "s"(hi1), "s"(0x0000ffff00000000ull));
-    }
-    float m = max_raw(-100.0f, sm);
-    float cur = band_db;
-    const float sd[8] = {sd0.x, sd0.y, sd0.z, sd0.w, sd1.x, sd1.y, sd1.z, sd1.w};
-    // The copies are ROTATED by one lane per step: what enters lane 0 (channel 0's band 0) comes from lanes 63, 62, ...,
-    // which are idle lanes holding -inf, exactly like the lanes 31, 30, ... that feed channel 1's band 0 on lane 32. At
-    // the eighth step the values that started on lanes 24 and 56 (band 24 of either channel) would arrive: they are cut
-    // off one step earlier, on lanes 31 and 63.
-#pragma unroll
-    for (int d = 1; d <= 8; d++) {
-        if (d == 8) cur = (lane & 31) == 31 ? ninf : cur;
-        cur = ror1(cur);   // band_db[lane - d]
-        m = max_raw(m, cur + sd[d - 1]);
+        asm("v_mov_b32 %[sm], %[b]\n\t"
+            "s_nop 0\n\t"
+            "v_mov_b32_dpp %[cur], %[b] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32 %[t], %[cur], %[s1]\n\t"
+            "v_max_f32_dpp %[sm], %[sm], %[sm] row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32 %[acc], %[t]\n\t"
+            "v_mov_b32_dpp %[cur], %[cur] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32 %[t], %[cur], %[s2]\n\t"
+            "v_max_f32_dpp %[sm], %[sm], %[sm] row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32 %[acc], %[acc], %[t]\n\t"
+            "v_mov_b32_dpp %[cur], %[cur] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32 %[t], %[cur], %[s3]\n\t"
+            "v_max_f32_dpp %[sm], %[sm], %[sm] row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32 %[acc], %[acc], %[t]\n\t"
+            "v_mov_b32_dpp %[cur], %[cur] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32 %[t], %[cur], %[s4]\n\t"
+            "v_max_f32_dpp %[sm], %[sm], %[sm] row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_max_f32 %[acc], %[acc], %[t]\n\t"
+            "v_mov_b32_dpp %[cur], %[cur] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32 %[t], %[cur], %[s5]\n\t"
+            "v_max_f32 %[acc], %[acc], %[t]\n\t"
+            "v_mov_b32_dpp %[cur], %[cur] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32 %[t], %[cur], %[s6]\n\t"
+            "v_max_f32 %[acc], %[acc], %[t]\n\t"
+            "v_mov_b32_dpp %[cur], %[cur] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32 %[t], %[cur], %[s7]\n\t"
+            "s_mov_b64 vcc, %[cut]\n\t"
+            "v_cndmask_b32_e32 %[cur], %[cur], %[ninf], vcc\n\t"
+            "v_max_f32 %[acc], %[acc], %[t]\n\t"
+            "v_readlane_b32 %[h0], %[sm], 16\n\t"
+            "v_mov_b32_dpp %[cur], %[cur] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32 %[t], %[cur], %[s8]\n\t"
+            "v_readlane_b32 %[h1], %[sm], 48\n\t"
+            "v_max_f32 %[acc], %[acc], %[t]\n\t"
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_mov_b64 exec, 0xffff\n\t"
+            "v_max_f32 %[sm], %[h0], %[sm]\n\t"
+            "s_mov_b64 exec, %[m2]\n\t"
+            "v_max_f32 %[sm], %[h1], %[sm]\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "v_max3_f32 %[acc], %[sm], %[acc], %[lo]"
+            : [sm] "=&v"(sm), [cur] "=&v"(cur), [acc] "=&v"(m), [t] "=&v"(tt), [h0] "=&s"(h0), [h1] "=&s"(h1), [sv] "=&s"(sv)
+            : [b] "v"(band_db), [s1] "v"(sd0.x), [s2] "v"(sd0.y), [s3] "v"(sd0.z), [s4] "v"(sd0.w), [s5] "v"(sd1.x), [s6] "v"(sd1.y),
+              [s7] "v"(sd1.z), [s8] "v"(sd1.w), [ninf] "v"(ninf), [cut] "s"(0x8000000080000000ull), [m2] "s"(0x0000ffff00000000ull),
+              [lo] "s"(-100.0f)
+            : "vcc");
     }
     const float g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 0));
     const float g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 32));
@@ -918,6 +955,10 @@ __device__ __forceinline__ float spread_threshold_2(const int lane, float energy
         }
     }
     return m + (-6.0f);
+}
+__device__ __forceinline__ float spread_threshold_2(const int lane, float energy, float rcount, const LossyDevTables &T) {
+    const float4 sd0 = T.pack[kRowS10 * 64], sd1 = T.pack[kRowS10 * 64 + 1];
+    return spread_threshold_2r(lane, energy, rcount, sd0, sd1, T);
 }
 
 // amplitude-domain threshold of a masking level s (dB): 10^((smr_thr + fl(s - 10)) / 20), hardware exp2

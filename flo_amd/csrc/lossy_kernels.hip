@@ -1389,19 +1389,60 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
         unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
-        // The frame loop is software-pipelined by one phase: the masking pass of frame h - one long dependent chain on 50
-        // lanes (logarithm, DPP maxima, exponential, division) - and the fold of frame h + 1, which only needs PCM that is
-        // already in registers, sit in the same basic block, so the fold's packed arithmetic fills the issue slots the
-        // chain leaves empty. Entering frame h, (zr, zi) hold its folded input; `fh` is the half-frame the next fold
-        // takes first and `nh` the free register set the half after it is loaded into, at the TOP of the frame.
+        // The frame loop is software-pipelined by two phases. (1) The fold of frame h + 1, which only needs PCM that is already
+        // in registers, runs at the end of frame h: entering frame h, (zr, zi) hold its folded input, and the half-frame
+        // after next is loaded at the TOP of the frame into the registers the last fold freed. (2) The masking pass of
+        // frame h - one long dependent chain on 50 lanes (logarithm, DPP maxima, exponential, division), 6.6 % of the launch
+        // when it runs by itself - is deferred into frame h + 1's FFT, behind the issue of the first exchange's reads: it
+        // fills the LDS round trip the wave would otherwise sit out (a wave issues in order). The packer learns a frame's
+        // band tables a third of a frame later and takes its coefficients correspondingly early (take_next).
         v2f zr[8], zi[8];
         if (!COEFFS) fold_2(lane_id_opaque(), ae, ao, be, bo, zr, zi, T);
+        float pend_e = 0.f, pend_m = 0.f;   // band energies / maxima of the frame whose masking pass is pending
+        // masking level, temporal masking, scale factors of frame gp (clip frame hp) from its band statistics; publishes them
+        auto mask_publish = [&](const int ln, const uint32_t gp, const unsigned hp, const float energy1, const float bmax1,
+                                const float rcount, const float4 sd0, const float4 sd1) __attribute__((always_inline)) {
+            const int bnd = ln & 31, up = ln >> 5;
+#if (FLO_SKIP & 16) == 0
+            // (the scale factors first: their division and logarithm are a chain of their own, and in front of the masking
+            // pass - which ends in a branch - they share its basic block and fill its dependent-issue gaps)
+            const float bm = bmax1;
+            const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
+            const uint32_t sfw1 = sf_word(sfv1);
+            const float a = spread_threshold_2r(ln, energy1, rcount, sd0, sd1, T);
+            const float sl = max_raw(a, prev * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
+            prev = sl;
+            const float tl1 = masking_amplitude(sl, T.smr_thr);
+#else   // diagnostic (results invalid): what the masking pass costs
+            const float bm = bmax1, tl1 = energy1 * 1e-3f + rcount + sd0.x + sd1.y, sfv1 = bm * 100.f + 1.f;
+            const uint32_t sfw1 = __float_as_uint(tl1) >> 16;
+#endif
+            // bands with anything above their masking amplitude: channel 0's on bits 0..24, channel 1's on bits 32..56
+            const unsigned long long al = __ballot(bnd < 25 && bm > tl1);
+            if (bnd < 25) {
+                typedef __attribute__((address_space(3))) float lds_f32;
+                const uint32_t ts_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)cs.ts[gp & 1u]);
+                lds_f32 *tp = reinterpret_cast<lds_f32 *>((uintptr_t)(ts_s + 16u * (uint32_t)bnd + 4u * (uint32_t)up));
+                tp[0] = tl1;
+                tp[2] = sfv1;
+                cs.sfwh[gp & 1u][up][bnd] = (uint16_t)sfw1;
+            }
+            if (ln == 0) {
+                cs.alive[gp & 1u][0] = (uint32_t)al;
+                cs.alive[gp & 1u][1] = (uint32_t)(al >> 32);
+            }
+            if (DBG && A.dbg_sfw && bnd < 25) A.dbg_sfw[((frame0 + hp) * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
+            set_counter(&cs.ts_ready, gp + 1);
+        };
         auto frame_body = [&](const unsigned h, v2f (&ne)[8], v2f (&no)[8], v2f (&fe)[8], v2f (&fo)[8]) __attribute__((always_inline)) {
             const int ln = lane_id_opaque();
             const uint32_t g = fbase + h;
             FLO_MARK("frame_begin");
             // has the packer taken the previous frame's coefficients out of the buffer? (asked now, needed at the first exchange)
             const uint32_t consumed_early = peek_counter(&cs.consumed);
+            // the masking pass's constants, fetched ahead of the exchange it runs behind (it must not wait for LDS there)
+            const float4 sd0 = T.pack[kRowS10 * 64], sd1 = T.pack[kRowS10 * 64 + 1];
+            const float rcount = T.pack[kRowLane * 64 + ln].z;   // (the row holds band (lane & 31)'s value on every lane)
             v2f c[16];
             if (COEFFS) {
 #pragma unroll
@@ -1424,7 +1465,9 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
                 STAMP(1);
                 if ((uint32_t)__builtin_amdgcn_readfirstlane((int)consumed_early) < g) wait_counter(&cs.consumed, g);
                 STAMP(7);
-                fft512_2(ln, zr, zi, cs.u.xch4, T);
+                fft512_2(ln, zr, zi, cs.u.xch4, T, [&]() __attribute__((always_inline)) {
+                    if (h > 0) mask_publish(ln, g - 1u, h - 1u, pend_e, pend_m, rcount, sd0, sd1);   // uniform
+                });
                 FLO_MARK("fft_done");
                 STAMP(2);
                 post_rotate_transpose_2(ln, zr, zi, cs.u.coef2, c, T);
@@ -1440,51 +1483,29 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
                 }
             }
             set_counter(&cs.coef_ready, g + 1);
-            // band statistics, masking level, temporal masking, scale factors (both channels)
-            float energy1, bmax1;   // channel 0's band b on lane b, channel 1's on lane 32 + b
+            // band statistics (both channels): channel 0's band b on lane b, channel 1's on lane 32 + b
+            float energy1, bmax1;
             band_stats_2<DIRTY>(ln, c, cs.slot, T, energy1, bmax1);
             FLO_MARK("bandstats_done");
             STAMP(4);
-            const int bnd = ln & 31, up = ln >> 5;
-            const float rcount = T.pack[kRowLane * 64 + ln].z;   // (the row holds band (lane & 31)'s value on every lane)
-            // the next frame's fold: independent of the masking pass below (no memory clobber between the two; in front of it
-            // in program order because the pass ends in a rarely taken branch that would fence the scheduler)
-            if (!COEFFS) fold_2(ln, fe, fo, ne, no, zr, zi, T);
-#if (FLO_SKIP & 16) == 0
-            const float a = spread_threshold_2(ln, energy1, rcount, T);
-            const float sl = max_raw(a, prev * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
-            prev = sl;
-            const float tl1 = masking_amplitude(sl, T.smr_thr);
-            const float bm = bmax1;
-            const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
-            const uint32_t sfw1 = sf_word(sfv1);
-#else   // diagnostic (results invalid): what the masking pass costs
-            const float bm = bmax1, tl1 = energy1 * 1e-3f + rcount, sfv1 = bm * 100.f + 1.f;
-            const uint32_t sfw1 = __float_as_uint(tl1) >> 16;
-#endif
-            // bands with anything above their masking amplitude: channel 0's on bits 0..24, channel 1's on bits 32..56
-            const unsigned long long al = __ballot(bnd < 25 && bm > tl1);
-            FLO_MARK("fold_done");
-            if (bnd < 25) {
-                typedef __attribute__((address_space(3))) float lds_f32;
-                const uint32_t ts_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)cs.ts[g & 1u]);
-                lds_f32 *tp = reinterpret_cast<lds_f32 *>((uintptr_t)(ts_s + 16u * (uint32_t)bnd + 4u * (uint32_t)up));
-                tp[0] = tl1;
-                tp[2] = sfv1;
-                cs.sfwh[g & 1u][up][bnd] = (uint16_t)sfw1;
+            if (COEFFS) {
+                mask_publish(ln, g, h, energy1, bmax1, rcount, sd0, sd1);
+            } else {
+                pend_e = energy1, pend_m = bmax1;
+                // the next frame's fold
+                fold_2(ln, fe, fo, ne, no, zr, zi, T);
             }
-            if (ln == 0) {
-                cs.alive[g & 1u][0] = (uint32_t)al;
-                cs.alive[g & 1u][1] = (uint32_t)(al >> 32);
-            }
-            if (DBG && A.dbg_sfw && bnd < 25) A.dbg_sfw[((frame0 + h) * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
-            set_counter(&cs.ts_ready, g + 1);
             FLO_MARK("frame_end");
             STAMP(5);
         };
         for (unsigned h = 0; h < hops; h += 2) {
             frame_body(h, ae, ao, be, bo);
             if (h + 1 < hops) frame_body(h + 1, be, bo, ae, ao);
+        }
+        if (!COEFFS && hops) {   // the last frame's masking pass has no FFT to hide behind
+            const int ln = lane_id_opaque();
+            const float4 sd0 = T.pack[kRowS10 * 64], sd1 = T.pack[kRowS10 * 64 + 1];
+            mask_publish(ln, fbase + hops - 1u, hops - 1u, pend_e, pend_m, T.pack[kRowLane * 64 + ln].z, sd0, sd1);
         }
 #ifdef FLO_STAMPS
         if (A.dbg_stamps && lane == 0) {   // [13]: where the wave ran (HW_ID, XCC_ID, clip slot): diag/stamps_clips.py groups the records by it
