@@ -537,8 +537,7 @@ extern "C" int flo_batch_fill_synthetic(flo_batch *b, uint32_t seed, uint64_t cl
 // auto selection of the lossy kernel form (flo_batch_encode with which = 0 and nothing forced)
 static int auto_form(const flo_batch *b) {
     if (b->ch > 2) return 2;
-    static const int stereo_chain = [] { const char *e = getenv("FLO_CHAIN2Q"); return e && atoi(e) == 0 ? 4 : 5; }();
-    return (b->n_clips * b->ch >= 512) ? (b->ch == 2 ? stereo_chain : 1) : 2;
+    return (b->n_clips * b->ch >= 512) ? (b->ch == 2 ? 5 : 1) : 2;
 }
 // scratch of the frame-parallel form: per-frame masking levels, fixed-size frame slots, frame offsets
 static int alloc_frame_scratch(flo_batch *b) {
@@ -622,30 +621,21 @@ static int batch_encode_launch(flo_batch *b, int which) {
     if (which == 0) which = auto_form(b);
     if (b->ch > 2) which = 2;   // more than two channels: the generic frame-parallel kernels
     int rc;
-    if ((which == 4 || which == 5) && b->exact) which = 3;
-    if (which == 5 && b->ch == 2) {   // stereo: transform wave + (quantiser and packer) wave per clip
+    if (which == 3 || which == 4) which = 5;   // (earlier rounds' stereo chain forms: retired, the numbers stay valid)
+    if (which == 5 && (b->exact || b->ch != 2)) which = 1;   // the exact-threshold yardstick and mono live in the one-wave-per-channel form
+    if (which == 5) {   // stereo: one lock-step transform wave + one quantiser-and-packer wave per clip
 #ifdef FLO_STAMPS
         if (!b->d_stamps) HIPCHK(c, pool_alloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
 #endif
         LossyArgs A = make_args(b);
         HIPCHK(c, hipMemsetAsync(b->d_next, 0, 4, c->stream));   // the batch-wide clip counter of the persistent workgroups
         rc = timed_launch(c, "lossy_chain2q", [&] { return launch_lossy_chain2q(A, c->stream); });
-    } else if (which == 4 && b->ch == 2) {   // stereo: one lock-step transform wave + one packer wave per clip
-#ifdef FLO_STAMPS
-        if (!b->d_stamps) HIPCHK(c, pool_alloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
-#endif
-        LossyArgs A = make_args(b);
-        HIPCHK(c, hipMemsetAsync(b->d_next, 0, 4, c->stream));   // the batch-wide clip counter of the persistent workgroups
-        rc = timed_launch(c, "lossy_chain2x", [&] { return launch_lossy_chain2x(A, c->stream); });
-    } else if (which == 1 || ((which == 3 || which == 4 || which == 5) && b->ch != 2)) {
+    } else if (which == 1) {
 #ifdef FLO_STAMPS
         if (!b->d_stamps) HIPCHK(c, pool_alloc(&b->d_stamps, b->n_clips * b->ch * 16 * 8));
 #endif
         LossyArgs A = make_args(b);
         rc = timed_launch(c, "lossy_chain", [&] { return launch_lossy_chain(A, c->stream); });
-    } else if (which == 3) {   // stereo pipeline: two channel waves + one packer wave per clip
-        LossyArgs A = make_args(b);
-        rc = timed_launch(c, "lossy_chain3", [&] { return launch_lossy_chain3(A, c->stream); });
     } else {   // frame-parallel form
         // allocated by flo_batch_create when this form is what auto selects; only a forced form allocates here
         int arc = alloc_frame_scratch(b);
@@ -718,7 +708,7 @@ static int batch_sync_impl(flo_batch *b, hipEvent_t done) {
                 for (size_t w = 0; w < b->n_clips * b->ch; w++)
                     for (int i = 0; i < 14; i++) sum[i] += (double)st[w * 16 + i];
                 double frames = (double)b->total_frames * b->ch;
-                if (b->ch == 2 && (c->force_path == 4 || c->force_path == 5 || c->force_path == 0)) {   // lock-step forms: wave 0 = transform, wave 1 = packer
+                if (b->ch == 2 && (c->force_path >= 3 || c->force_path == 0)) {   // lock-step form: wave 0 = transform, wave 1 = packer
                     double t[14] = {0}, p[14] = {0};
                     for (size_t k = 0; k < b->n_clips; k++)
                         for (int i = 0; i < 14; i++) { t[i] += (double)st[(2 * k) * 16 + i]; p[i] += (double)st[(2 * k + 1) * 16 + i]; }
@@ -729,7 +719,7 @@ static int batch_sync_impl(flo_batch *b, hipEvent_t done) {
                     for (int i = 0; i < 9; i++) { fprintf(stderr, " %s=%.1f", tn[i], t[i] / b->total_frames); tt += t[i]; }
                     fprintf(stderr, " total=%.1f | P:", tt / b->total_frames);
                     for (int i = 0; i < 6; i++) { fprintf(stderr, " %s=%.1f", pn[i], p[i] / b->total_frames); pt += p[i]; }
-                    fprintf(stderr, " total=%.1f", pt / b->total_frames);
+                    fprintf(stderr, " total=%.1f item-form declined %.4f of channel-frames", pt / b->total_frames, p[6] / (2.0 * b->total_frames));
                     fprintf(stderr, " | T waits>1000: %.2f%% of frames, %.0f cyc/frame avg; >5000: %.2f%%, %.0f | P busy>12000: %.2f%%, %.0f; >20000: %.2f%%, %.0f\n",
                             100 * t[10] / b->total_frames, t[9] / b->total_frames, 100 * t[12] / b->total_frames, t[11] / b->total_frames,
                             100 * p[10] / b->total_frames, p[9] / b->total_frames, 100 * p[12] / b->total_frames, p[11] / b->total_frames);

@@ -1071,9 +1071,11 @@ struct StereoLds {
 // a segment (T.dirty, a uniform bitmap) skip the store and the restart multiplication (x 1.0 for every lane); and the
 // two halves of a band meet through ONE swap per quantity that also sorts the channels: the result has channel 0's
 // band b on lane b and channel 1's on lane 32 + b, which is what the merged masking pass consumes.
-template <uint32_t DIRTY = 0xFFFFu>
+// SO_PRE: the twelve gather addresses (so_pre) and the zero slot were prepared once by the caller (band_stats_2_prepare), whose
+// slot area is not shared with anything else: fifteen instructions per frame less.
+template <uint32_t DIRTY = 0xFFFFu, bool SO_PRE = false>
 __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16], float4 *slot, const LossyDevTables &T,
-                                             float &energy1, float &bmax1) {
+                                             float &energy1, float &bmax1, const uint32_t *so_pre = nullptr) {
     // Slot addresses as 32-bit LDS offsets from ONE scalar base (as the sum of the clip's LDS base and the member offset
     // the compiler re-added both terms for every access); the accesses go through address-space-3 pointers so that they
     // stay ds_* instructions. A slot is 16 bytes (sums of both channels, maxima of both channels): ONE ds_write_b128 per
@@ -1084,7 +1086,7 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
     const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)slot);
     // the zero slot shares storage with the exchange buffer: written every frame (lane l writes dword l & 3: no branch, one
     // register of zeros, a 4-byte store instead of a 16-byte one)
-    {
+    if (!SO_PRE) {
         typedef __attribute__((address_space(3))) float lds_f32;
         float z = 0.f;
         asm volatile("" : "+v"(z));   // not a loop invariant: four registers of zeros held across the frame loop were spilled
@@ -1093,9 +1095,13 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
     uint32_t so[12];
 #pragma unroll
     for (int g = 0; g < 3; g++) {
-        const float4 lst = T.pack[(kRowLst + g) * 64 + lane];
-        so[4 * g + 0] = s0 + 2u * __float_as_uint(lst.x), so[4 * g + 1] = s0 + 2u * __float_as_uint(lst.y);
-        so[4 * g + 2] = s0 + 2u * __float_as_uint(lst.z), so[4 * g + 3] = s0 + 2u * __float_as_uint(lst.w);
+        if (SO_PRE) {
+            so[4 * g + 0] = so_pre[4 * g + 0], so[4 * g + 1] = so_pre[4 * g + 1], so[4 * g + 2] = so_pre[4 * g + 2], so[4 * g + 3] = so_pre[4 * g + 3];
+        } else {
+            const float4 lst = T.pack[(kRowLst + g) * 64 + lane];
+            so[4 * g + 0] = s0 + 2u * __float_as_uint(lst.x), so[4 * g + 1] = s0 + 2u * __float_as_uint(lst.y);
+            so[4 * g + 2] = s0 + 2u * __float_as_uint(lst.z), so[4 * g + 3] = s0 + 2u * __float_as_uint(lst.w);
+        }
     }
     const uint32_t dirty = DIRTY;   // compile-time: straight-line code
     v4f am = {0.f, 0.f, 0.f, 0.f};   // running (sum left, sum right, max left, max right): one register quad, stored as it is
@@ -1169,6 +1175,18 @@ __device__ __forceinline__ void band_stats_2(const int lane, const v2f (&c)[16],
         bmax1 = max_raw(__int_as_float(m2[0]), __int_as_float(m2[1]));
     }
     wave_sync();
+}
+
+// once per launch, for band_stats_2<., true>: the zero slot and the gather addresses of this lane
+__device__ __forceinline__ void band_stats_2_prepare(const int lane, float4 *slot, const float4 *pack, uint32_t (&so)[12]) {
+    const uint32_t s0 = (uint32_t)(uintptr_t)slot;
+    if (lane < 4) reinterpret_cast<float *>(slot + kZeroSlot)[lane] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const float4 lst = pack[(kRowLst + g) * 64 + lane];
+        so[4 * g + 0] = s0 + 2u * __float_as_uint(lst.x), so[4 * g + 1] = s0 + 2u * __float_as_uint(lst.y);
+        so[4 * g + 2] = s0 + 2u * __float_as_uint(lst.z), so[4 * g + 3] = s0 + 2u * __float_as_uint(lst.w);
+    }
 }
 
 // The band-offset rows of the quantiser (what its gathers wait for). The chain kernel fetches them BEFORE the masking

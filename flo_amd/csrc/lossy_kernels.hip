@@ -1,15 +1,19 @@
 // lossy_kernels.hip — gfx950 kernels of the lossy encode path and their launchers.
 //
-//   lossy_chain3_kernel      stereo batches (the default): two channel wavefronts per clip run transform, masking
-//                            and quantiser of frame t + 1 while a packer wavefront serialises and flushes frame t.
+//   lossy_chain2q_kernel     stereo batches (the default and the benchmarked kernel): per clip one TRANSFORM wave that carries
+//                            both channels in lock-step (packed f32) through fold, FFT, post-rotation, band statistics and
+//                            masking pass, and one PACKER wave that quantises, serialises and flushes; persistent
+//                            workgroups deal the clips dynamically.
 //   lossy_chain_kernel<NW>   one wavefront per (clip, channel) walks the clip's frames in order (the psychoacoustic
 //                            model's 25-float temporal state, psychoacoustic.rs:198-203, lives in registers),
 //                            reads every PCM sample once and appends finished frame bytes to the clip's DATA
 //                            chunk: replaces the hot loop of TransformEncoder::encode_to_flo (encoder.rs:200-225).
+//                            Mono batches, and the independently written cross-check of the stereo form.
 //   lossy_frame_kernel<CH,P> frame-parallel form for few/long clips: P=1 computes only the per-band masking
 //                            level before temporal masking, lossy_scan_kernel resolves the recurrence, P=2
 //                            re-runs the transform and finishes each frame into a fixed slot; compact_kernel
-//                            packs the slots. lossy_frame_n_kernel<P> is the same for 3 to 8 channels.
+//                            packs the slots. lossy_frame2x_kernel is its stereo form built from the lock-step device
+//                            functions, lossy_frame_n_kernel<P> the same for 3 to 8 channels.
 //   All forms produce identical bytes (tests compare them file by file).
 #include <stdlib.h>
 
@@ -225,7 +229,6 @@ __device__ __forceinline__ void load_coeffs(const int lane, float (&c)[CH][16], 
 // so every PCM sample is read from HBM once. The two waves of a stereo clip meet twice per frame (LDS flag
 // hand-shakes, no workgroup barrier: other clips of the workgroup never wait) to assemble and flush the frame.
 constexpr int kPackBytes = kPackRows * 64 * 16;
-constexpr int kPackBytesHot = kPackRowsHot * 64 * 16;   // what lossy_chain2x_kernel keeps in LDS
 struct ClipLds {
     WaveLds<1> wl[2];
     __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 128];
@@ -406,31 +409,16 @@ __global__ __launch_bounds__(768, FLO_CHAIN_WAVES_PER_SIMD) void lossy_chain_ker
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------- three waves per clip
-// Stereo clips as a two-stage pipeline: the two channel waves do transform, masking and quantiser of frame t + 1 while
-// a third wave (the packer) plans, serialises and flushes frame t of both channels. The channel waves hand the
-// quantised integers over through 2 KiB of LDS per channel (16 x i16 per lane); nothing else crosses waves, so the
-// sparse offsets, the frame header and the flush need no rendezvous at all. Bytes are identical to the two-wave form.
-struct Clip3Lds {
-    WaveLds<1> wl[2];
-    __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 256];
-    __attribute__((aligned(16))) uint32_t qh[2][512];   // [channel]: the 1024 integers of a frame in natural order
-    uint16_t sfwh[2][32];
-    uint32_t runtab[kRunTabEntries];   // run table of the ballot-form packer (one channel at a time)
-    uint32_t ready[2];      // frames published by channel wave w
-    uint32_t consumed;      // frames the packer has taken over
-    uint32_t pad;
-};
-static_assert(sizeof(Clip3Lds) % 16 == 0, "clip LDS block keeps 16-byte alignment");
-
+// ---------------------------------------------------------------------------------------------- counters between the waves of a clip
 // wait until the LDS counter at `p` reaches `want` (written by another wave of this workgroup)
+template <int SLEEP = 1>
 __device__ __forceinline__ void wait_counter(const uint32_t *p, uint32_t want) {
     const uint32_t a = (uint32_t)(uintptr_t)p;
     uint32_t seen;
     do {
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(a) : "memory");
         if (seen >= want) break;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SLEEP);
     } while (true);
 }
 // publish: every LDS access this wave issued before is performed first (a wave's LDS instructions execute in order)
@@ -445,688 +433,38 @@ __device__ __forceinline__ void set_counter(uint32_t *p, uint32_t v) {
     asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
 }
 
-template <bool EXACT>
-__global__ __launch_bounds__(960) void lossy_chain3_kernel(LossyArgs A, int clips_per_wg) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63;
-    {
-        float4 *dstp = reinterpret_cast<float4 *>(lds_raw);
-        for (int i = tid; i < kPackRows * 64; i += (int)blockDim.x) dstp[i] = A.T.pack[i];
-        for (int i = tid; i < clips_per_wg; i += (int)blockDim.x) {
-            Clip3Lds &c0 = *reinterpret_cast<Clip3Lds *>(lds_raw + kPackBytes + (size_t)i * sizeof(Clip3Lds));
-            c0.ready[0] = 0;
-            c0.ready[1] = 0;
-            c0.consumed = 0;
-        }
-    }
-    __syncthreads();
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Role of this wave: 0, 1 = channel waves, 2 = packer. A packer wave issues about a third more instructions per
-    // frame than a channel wave, and waves land on the four SIMDs round-robin by index; with five clips (15 waves)
-    // the roles are dealt so that every SIMD carries three channel waves and one packer, or two packers and one
-    // channel wave on the SIMD that hosts only three waves (0x... tables below: 4 bits per wave).
-    int cl, w;
-    if (clips_per_wg == 5) {
-        //            wave:  0 1 2 3 4 5 6 7 8 9 10 11 12 13 14
-        // role              C C C P C C C P C C  C  C  P  P  P
-        const unsigned long long role_tab = 0x222101021012010ull;   // channel index (0/1) or 2
-        const unsigned long long clip_tab = 0x432443312210100ull;   // clip slot
-        w = (int)((role_tab >> (4 * wv)) & 15ull);
-        cl = (int)((clip_tab >> (4 * wv)) & 15ull);
-    } else {
-        cl = wv / 3;
-        w = wv % 3;
-    }
-    const unsigned clip = blockIdx.x * (unsigned)clips_per_wg + (unsigned)cl;
-    if (clip >= (unsigned)A.n_clips) return;
-    Clip3Lds &cs = *reinterpret_cast<Clip3Lds *>(lds_raw + kPackBytes + (size_t)cl * sizeof(Clip3Lds));
-    const unsigned hops = A.clip_hops[clip];
-    const unsigned long long frame0 = A.clip_frame0[clip];
-
-#ifdef FLO_PACKER_GENERAL
-    if (w == 2) {
-        // ------------------------------------------------------------------ packer
-        uint8_t *stage = cs.stage;
-        uint8_t *gout = A.out + A.out_off[clip];
-        unsigned long long written = 0;
-        uint32_t pend = 0, tailb = 0;
-        for (unsigned h = 0; h < hops; h++) {
-            const int ln = lane_id_opaque();
-            wait_counter(&cs.ready[0], h + 1);
-            wait_counter(&cs.ready[1], h + 1);
-            // the values stay packed: element 2k is the low half of a dword (the stores below only look at its low 16
-            // bits), element 2k + 1 its high half; the non-zero masks come straight from the packed words
-            int q[2][16];
-            uint32_t sfw[2], msk[2];
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(cs.qh[ch]);
-                const uint4 x0 = src[ln], x1 = src[64 + ln];
-                const uint32_t xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                uint32_t hi[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    hi[k] = xs[k] >> 16;
-                    q[ch][2 * k] = (int)xs[k];
-                    q[ch][2 * k + 1] = (int)hi[k];
-                }
-                msk[ch] = nonzero_mask16_packed(xs, hi);
-                sfw[ch] = cs.sfwh[ch][ln & 31];
-            }
-            set_counter(&cs.consumed, h + 1);
-            SparsePlan P[2];
-            sparse_plan_m(ln, msk[0], P[0]);
-            sparse_plan_m(ln, msk[1], P[1]);
-            uint32_t tot[2] = {P[0].total, P[1].total};
-            // the < 16 bytes the previous frame left unflushed go back to the front of the staging buffer
-            if (ln < (int)pend) stage[ln] = (uint8_t)tailb;
-            const uint32_t flen = emit_frame<2>(ln, stage + pend, 2, 0, tot, sfw, P, q);
-            wave_sync();
-            if (ln == 0) A.frame_size[frame0 + h] = flen;
-            const uint32_t have = pend + flen;
-            const uint32_t n16 = have >> 4;
-            const uint4 *src = reinterpret_cast<const uint4 *>(stage);
-            uint4 *dst = reinterpret_cast<uint4 *>(gout + written);
-            for (uint32_t i = ln; i < n16; i += 64) dst[i] = src[i];
-            pend = have & 15u;
-            tailb = (ln < (int)pend) ? stage[(n16 << 4) + ln] : 0u;
-            written += (unsigned long long)n16 << 4;
-            wave_sync();
-        }
-        if (lane < (int)pend) gout[written + lane] = (uint8_t)tailb;
-        if (lane == 0) A.clip_bytes[clip] = written + pend;
-        return;
-    }
-
-#else
-    if (w == 2) {
-        // ------------------------------------------------------------------ packer
-        // Frame bytes (writer.rs:236-254 + encoder.rs:243-280) are composed in the staging buffer behind the < 16 bytes
-        // the previous frame left unflushed: [253][1024 u32][0][blob_len u32][0][2] | 2 x 25 scale words |
-        // per channel [len u32][sparse blob]. Each channel's blob comes from the ballot-form packer; a dense frame it
-        // declines goes through the general form (same bytes, tests compare them).
-        uint8_t *stage = cs.stage;
-        uint8_t *gout = A.out + A.out_off[clip];
-        unsigned long long written = 0;
-        uint32_t pend = 0, tailb = 0;
-        const uint32_t tab_a = (uint32_t)(uintptr_t)cs.runtab;
-        for (unsigned h = 0; h < hops; h++) {
-            const int ln = lane_id_opaque();
-            wait_counter(&cs.ready[0], h + 1);
-            wait_counter(&cs.ready[1], h + 1);
-            // hand-over buffer of a channel: the 1024 integers in natural order (value p at halfword p). xd[k] = the dword
-            // with positions 128 k + 2 lane and + 1 (what the block-form packer takes); xs = the lane's 16 contiguous values
-            // (general form only)
-            uint32_t xd[2][8], xs[2][8], sfw[2];
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++) {
-                const uint32_t *hv = cs.qh[ch];
-#pragma unroll
-                for (int k = 0; k < 8; k++) xd[ch][k] = hv[64 * k + ln];
-                const uint4 *src = reinterpret_cast<const uint4 *>(cs.qh[ch]);
-                const uint4 x0 = src[2 * ln], x1 = src[2 * ln + 1];
-                xs[ch][0] = x0.x, xs[ch][1] = x0.y, xs[ch][2] = x0.z, xs[ch][3] = x0.w;
-                xs[ch][4] = x1.x, xs[ch][5] = x1.y, xs[ch][6] = x1.z, xs[ch][7] = x1.w;
-                sfw[ch] = cs.sfwh[ch][ln & 31];
-            }
-            set_counter(&cs.consumed, h + 1);
-#if FLO_ABLATE3 >= 1
-            for (int e = 0; e < 8; e++) { FLO_KEEP(xd[0][e]); FLO_KEEP(xd[1][e]); }
-            for (int e = 0; e < 8; e++) { FLO_KEEP(xs[0][e]); FLO_KEEP(xs[1][e]); }
-            continue;
-#endif
-            // the < 16 bytes the previous frame left unflushed go back to the front of the staging buffer
-            if (ln < (int)pend) stage[ln] = (uint8_t)tailb;
-            uint8_t *f = stage + pend;
-            const uint32_t f_a = (uint32_t)(uintptr_t)f;
-            if (ln < 25) {
-#pragma unroll
-                for (int ch = 0; ch < 2; ch++) {
-                    uint8_t *p = f + 12 + 50 * ch + 2 * ln;
-                    lds_st8<0>(p, sfw[ch]);
-                    lds_st8<1>(p, sfw[ch] >> 8);
-                }
-            }
-            uint32_t tot[2];
-            uint32_t pos = 112;   // 12 + 50 * 2: length word of channel 0
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++) {
-                uint32_t t = sparse_block_pack(ln, xd[ch], f_a + pos + 4u, tab_a);
-                if (t == kSparseFallback) {   // uniform: dense frame (a run longer than 255, or more than 126 runs)
-                    int q[1][16];
-                    uint32_t hi[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        hi[k] = xs[ch][k] >> 16;
-                        q[0][2 * k] = (int)xs[ch][k];
-                        q[0][2 * k + 1] = (int)hi[k];
-                    }
-                    SparsePlan P[1];
-                    sparse_plan_m(ln, nonzero_mask16_packed(xs[ch], hi), P[0]);
-                    uint8_t *const dsts[1] = {f + pos + 4};
-                    // trash bytes of the general form: the tail of the staging buffer, two per lane
-                    const uint32_t trash[1] = {(uint32_t)((stage + kFrameCap + 64 + 2 * ln) - dsts[0])};
-                    sparse_emit_n<1>(ln, q, P, dsts, trash);
-                    t = P[0].total;
-                }
-                tot[ch] = t;
-                if (ln == 32 + ch) {
-                    uint8_t *p = f + pos;
-                    p[0] = (uint8_t)t; p[1] = (uint8_t)(t >> 8); p[2] = (uint8_t)(t >> 16); p[3] = (uint8_t)(t >> 24);
-                }
-                pos += 4u + t;
-            }
-            const uint32_t flen = pos, blob_len = flen - 10;
-            if (ln == 0) {
-                f[0] = 253;
-                f[1] = 0x00; f[2] = 0x04; f[3] = 0; f[4] = 0;  // frame_samples = 1024
-                f[5] = 0;
-                f[6] = (uint8_t)blob_len; f[7] = (uint8_t)(blob_len >> 8); f[8] = (uint8_t)(blob_len >> 16); f[9] = (uint8_t)(blob_len >> 24);
-                f[10] = 0;  // BlockSize::Long
-                f[11] = 2;
-                A.frame_size[frame0 + h] = flen;
-            }
-            wave_sync();
-            const uint32_t have = pend + flen;
-            const uint32_t n16 = have >> 4;
-            const uint4 *src = reinterpret_cast<const uint4 *>(stage);
-            uint4 *dst = reinterpret_cast<uint4 *>(gout + written);
-            for (uint32_t i = ln; i < n16; i += 64) dst[i] = src[i];
-            pend = have & 15u;
-            tailb = (ln < (int)pend) ? stage[(n16 << 4) + ln] : 0u;
-            written += (unsigned long long)n16 << 4;
-            wave_sync();
-        }
-        if (lane < (int)pend) gout[written + lane] = (uint8_t)tailb;
-        if (lane == 0) A.clip_bytes[clip] = written + pend;
-        return;
-    }
-
-#endif
-    // ---------------------------------------------------------------------- channel waves
-    WaveLds<1> &lds = cs.wl[w];
-    if (lane == 0) lds.slots[0][kZeroSlot] = make_float2(0.f, 0.f);
-    LossyDevTables T = A.T;
-    T.pack = reinterpret_cast<const float4 *>(lds_raw);
-    const float *pcm = A.pcm + A.clip_off[clip];
-
-    FrameState<1> st;
-    st.prev[0] = 0.f;
-    float ae[1][8], ao[1][8], be[1][8], bo[1][8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) ae[0][r] = ao[0][r] = 0.f;  // pre-roll: 1024 zeros (encoder.rs:177)
-    if (!A.in_coeffs) {
-        load_half_fast<1>(lane, pcm, 2, w, 0, be, bo);   // the batch pads every clip with zeros to hops * 1024 sample-frames
-    }
-    auto frame_body = [&](const unsigned h, float (&pe)[1][8], float (&po)[1][8], float (&ce)[1][8],
-                          float (&co)[1][8]) __attribute__((always_inline)) {
-        const int ln = lane_id_opaque();
-        {
-            unsigned zero = 0;  // keep the (rarely used) global table out of loop-invariant registers
-            asm volatile("" : "+s"(zero));
-            T.ath_db += zero;
-        }
-        float c[1][16];
-        if (A.in_coeffs) {
-            load_coeffs<1>(ln, c, A, frame0 + h, w);
-        } else {
-            float zr[1][8], zi[1][8];
-            fold<1>(ln, pe, po, ce, co, zr, zi, T);
-            load_half_fast<1>(ln, pcm, 2, w, (long long)(h + 1) * 1024, pe, po);   // unconditional: see lossy_chain_kernel
-#if FLO_ABLATE3 >= 4
-            for (int r = 0; r < 8; r++) { FLO_KEEP(zr[0][r]); FLO_KEEP(zi[0][r]); }
-            wait_counter(&cs.consumed, h);
-            set_counter(&cs.ready[w], h + 1);
-            return;
-#endif
-            fft512<1>(ln, zr, zi, lds.u.xch, T);
-#if FLO_ABLATE3 >= 3
-            for (int r = 0; r < 8; r++) { FLO_KEEP(zr[0][r]); FLO_KEEP(zi[0][r]); }
-            wait_counter(&cs.consumed, h);
-            set_counter(&cs.ready[w], h + 1);
-            return;
-#endif
-            post_rotate_transpose<1>(ln, zr, zi, lds.u.coef, c, T);
-            store_coeffs_dbg<1>(ln, c, A, frame0 + h, w);
-        }
-#if FLO_ABLATE3 >= 2
-        for (int e = 0; e < 16; e++) FLO_KEEP(c[0][e]);
-        wait_counter(&cs.consumed, h);
-        set_counter(&cs.ready[w], h + 1);
-        return;
-#endif
-        int q[1][16];
-        uint32_t sfw[1];
-        SparsePlan P[1];
-        {
-            LaneConst L;
-            load_lane_const(ln, L, T);
-            analyse_frame<1, false, EXACT, false>(ln, c, lds, L, A, T, w, st, frame0 + h, q, sfw, P);
-        }
-        // hand over: sixteen i16 per lane as two uint4, the 25 scale words
-        uint32_t xs[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) xs[k] = __builtin_amdgcn_perm((uint32_t)q[0][2 * k + 1], (uint32_t)q[0][2 * k], 0x05040100u);
-        wait_counter(&cs.consumed, h);   // the packer has taken frame h - 1 out of the hand-over buffer
-        uint4 *dq = reinterpret_cast<uint4 *>(cs.qh[w]);   // natural order: the lane's 16 integers are 32 contiguous bytes
-        dq[2 * ln] = make_uint4(xs[0], xs[1], xs[2], xs[3]);
-        dq[2 * ln + 1] = make_uint4(xs[4], xs[5], xs[6], xs[7]);
-        if (ln < 25) cs.sfwh[w][ln] = (uint16_t)sfw[0];
-        set_counter(&cs.ready[w], h + 1);
-    };
-    for (unsigned h = 0; h < hops; h += 2) {
-        frame_body(h, ae, ao, be, bo);
-        if (h + 1 < hops) frame_body(h + 1, be, bo, ae, ao);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------- two waves per clip
-// Stereo clips, one TRANSFORM wave per clip that carries both channels in lock-step + the packer wave: every constant
-// row (window, twiddles, band tables) is read from LDS once per frame for both channels, the PCM comes in as float2
-// loads (both channels of a sample-frame), and the two channels are two independent dependency chains inside one
-// instruction stream, so a wait on LDS is shared by twice the work. Same device functions, same bytes as the other forms.
-struct Clip2xLds {
-    StereoLds wl;
-    __attribute__((aligned(16))) uint8_t stage[kFrameCap + 64 + 256];
-    __attribute__((aligned(16))) uint32_t qh[2][512];
-    uint16_t sfwh[2][32];
-    uint32_t runtab[kRunTabEntries];
-    uint32_t ready[2];      // frames published (both entries move together: the packer code is shared with the three-wave form)
-    uint32_t consumed;
-    uint32_t clip_seq;      // clips handed to the transform wave so far ...
-    uint32_t clip_cur;      // ... and the latest one
-    uint32_t pad[3];
-};
-static_assert(sizeof(Clip2xLds) % 16 == 0, "clip LDS block keeps 16-byte alignment");
-
 #ifndef FLO_C2X_THREADS
 #define FLO_C2X_THREADS 768
 #endif
-// COEFFS: the spectra come from A.in_coeffs (the quantiser-only test entry) instead of the transform. A compile-time
-// switch: as a run-time branch the two sources met in a phi and every frame paid 32 register copies for it.
-// DIRTY: the element positions (bit e of 16) at which some lane of the band table closes a segment; the other positions
-// skip the slot store and the restart multiplication of band_stats_2. 0xFFFF serves every table; the launcher picks the
-// instantiation made for 44.1 kHz when the table agrees.
+// DIRTY (template parameter of the lock-step chain kernel): the element positions (bit e of 16) at which some lane of the band
+// table closes a segment; the other positions skip the slot store and the restart multiplication of band_stats_2. 0xFFFF
+// serves every table; the launcher picks the instantiation made for 44.1 kHz when the table agrees.
 constexpr uint32_t kDirty44k = 0xBDBEu;
-// DBG: the stage outputs of the test entry points (coefficients, integers, scale words) are stored; the encode entry
-// points run the instantiation without them (no pointer tests, fewer live scalars in the frame loop).
-template <bool COEFFS, uint32_t DIRTY, bool DBG>
-__global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2x_kernel(LossyArgs A, int clips_per_wg) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63;
-    {
-        float4 *dstp = reinterpret_cast<float4 *>(lds_raw);
-        for (int i = tid; i < kPackRowsHot * 64; i += (int)blockDim.x) dstp[i] = A.T.pack[i];
-        for (int i = tid; i < clips_per_wg; i += (int)blockDim.x) {
-            Clip2xLds &c0 = *reinterpret_cast<Clip2xLds *>(lds_raw + kPackBytesHot + (size_t)i * sizeof(Clip2xLds));
-            c0.ready[0] = 0;
-            c0.ready[1] = 0;
-            c0.consumed = 0;
-            c0.clip_seq = 0;
-        }
-    }
-    __syncthreads();
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // waves 0 .. g-1 are the transform waves (one per SIMD first), waves g .. 2g-1 the packers
-    const int cl = wv % clips_per_wg;
-    const int w = wv < clips_per_wg ? 0 : 2;
-    Clip2xLds &cs = *reinterpret_cast<Clip2xLds *>(lds_raw + kPackBytesHot + (size_t)cl * sizeof(Clip2xLds));
-    // Clips are dealt dynamically: the workgroups are persistent (one per CU, the LDS holds no second one) and every
-    // (transform wave, packer wave) pair takes the next unclaimed clip of the batch when it has finished one, so CUs
-    // stay full until the batch runs out whatever the clip lengths. The packer claims (one atomic per clip) and tells
-    // its transform wave through LDS; frame counters run on across clips (fbase), so nothing is ever reset.
-    uint32_t fbase = 0, seq = 0;
-#ifdef FLO_PRIO_P
-    if (w == 2) __builtin_amdgcn_s_setprio(FLO_PRIO_P);
-#endif
-#ifdef FLO_PRIO_T
-    if (w != 2) __builtin_amdgcn_s_setprio(FLO_PRIO_T);
-#endif
-    for (;;) {
-    unsigned clip;
-    if (w == 2) {
-        unsigned got = 0;
-        if (lane == 0) got = atomicAdd(A.next_clip, 1u);
-        clip = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
-        if (lane == 0) cs.clip_cur = clip;
-        set_counter(&cs.clip_seq, ++seq);
-    } else {
-        wait_counter(&cs.clip_seq, ++seq);
-        clip = (unsigned)__builtin_amdgcn_readfirstlane((int)cs.clip_cur);
-    }
-    if (clip >= (unsigned)A.n_clips) return;
-    const unsigned hops = A.clip_hops[clip];
-    const unsigned long long frame0 = A.clip_frame0[clip];
-
-    if (w == 2) {
-        // ------------------------------------------------------------------ packer
-        // Frame bytes (writer.rs:236-254 + encoder.rs:243-280) are composed in the staging buffer behind the < 16 bytes
-        // the previous frame left unflushed: [253][1024 u32][0][blob_len u32][0][2] | 2 x 25 scale words |
-        // per channel [len u32][sparse blob]. Each channel's blob comes from the ballot-form packer; a dense frame it
-        // declines goes through the general form (same bytes, tests compare them).
-        uint8_t *stage = cs.stage;
-        uint8_t *gout = A.out + A.out_off[clip];
-        unsigned long long written = 0;
-        uint32_t pend = 0, tailb = 0;
-        const uint32_t tab_a = (uint32_t)(uintptr_t)cs.runtab;
-        uint32_t ready_early = 0;
-#ifdef FLO_STAMPS
-        unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
-#endif
-        for (unsigned h = 0; h < hops; h++) {
-            const int ln = lane_id_opaque();
-            if (ready_early < fbase + h + 1) {
-                wait_counter(&cs.ready[0], fbase + h + 1);
-                wait_counter(&cs.ready[1], fbase + h + 1);
-            }
-            STAMP(0);
-#ifdef FLO_STAMPS
-            const unsigned long long st_frame0 = st_last;
-#endif
-            // hand-over buffer of a channel: the 1024 integers in natural order (value p at halfword p). One dword per lane
-            // and 128 positions: xd[k] = positions 128 k + 2 lane and + 1 (what sparse_list_build ranks); xs = the lane's 16
-            // contiguous values (general form only).
-            uint32_t xd[2][8];
-            // (lanes 32..63 find their dword four further on or back: the transform wave swaps the two 16-byte halves of
-            // every other group of four lanes so that its own 16-byte stores fall on distinct banks)
-            const uint32_t ldw = (uint32_t)ln ^ (((uint32_t)ln >> 3) & 4u);
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++) {
-                const uint32_t *hv = cs.qh[ch];
-#pragma unroll
-                for (int k = 0; k < 8; k++) xd[ch][k] = hv[64 * k + ldw];
-            }
-            const uint32_t sfw_both = cs.sfwh[ln >> 5][ln & 31];   // scale words: lanes 0..24 left, 32..56 right
-            set_counter(&cs.consumed, fbase + h + 1);
-            STAMP(1);
-#if FLO_ABLATE3 >= 1
-            for (int e = 0; e < 8; e++) { FLO_KEEP(xd[0][e]); FLO_KEEP(xd[1][e]); }
-            continue;
-#endif
-            // the < 16 bytes the previous frame left unflushed go back to the front of the staging buffer
-            if (ln < (int)pend) stage[ln] = (uint8_t)tailb;
-            uint8_t *f = stage + pend;
-            const uint32_t f_a = (uint32_t)(uintptr_t)f;
-            if ((ln & 31) < 25) {
-                uint8_t *p = f + 12 + 50 * (ln >> 5) + 2 * (ln & 31);
-                lds_st8<0>(p, sfw_both);
-                lds_st8<1>(p, sfw_both >> 8);
-            }
-            uint32_t tot[2];
-            uint32_t pos = 112;   // 12 + 50 * 2: length word of channel 0
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++) {
-                uint32_t t = sparse_block_pack(ln, xd[ch], f_a + pos + 4u, tab_a);
-                if (t == kSparseFallback) {   // uniform: dense frame (many runs, a run longer than 255)
-                    // the general form wants the lane's 16 contiguous values: one trip through the (still unused) tail of
-                    // the staging buffer re-deals the dwords
-                    uint32_t *scr = reinterpret_cast<uint32_t *>(stage + 2560);
-#pragma unroll
-                    for (int k = 0; k < 8; k++) scr[64 * k + ln] = xd[ch][k];
-                    wave_sync();
-                    const uint4 x0 = reinterpret_cast<const uint4 *>(scr)[2 * ln], x1 = reinterpret_cast<const uint4 *>(scr)[2 * ln + 1];
-                    wave_sync();
-                    const uint32_t xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                    int q[1][16];
-                    uint32_t hi[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        hi[k] = xs[k] >> 16;
-                        q[0][2 * k] = (int)xs[k];
-                        q[0][2 * k + 1] = (int)hi[k];
-                    }
-                    SparsePlan P[1];
-                    sparse_plan_m(ln, nonzero_mask16_packed(xs, hi), P[0]);
-                    uint8_t *const dsts[1] = {f + pos + 4};
-                    // trash bytes of the general form: the tail of the staging buffer, two per lane
-                    const uint32_t trash[1] = {(uint32_t)((stage + kFrameCap + 64 + 2 * ln) - dsts[0])};
-                    sparse_emit_n<1>(ln, q, P, dsts, trash);
-                    t = P[0].total;
-                }
-                tot[ch] = t;
-                pos += 4u + t;
-                STAMP(2 + ch);
-            }
-            const uint32_t flen = pos, blob_len = flen - 10;
-            {
-                // the 12 header bytes [253][frame_samples = 1024 u32][0][blob_len u32][BlockSize::Long = 0][2 channels] and the
-                // two channel length words as ONE byte store: lane i < 12 holds header byte i, lanes 12..15 / 16..19 the bytes
-                // of the first / second length word (twenty single-lane byte stores and three exec branches before)
-                const uint32_t i = (uint32_t)ln;
-                const uint32_t w0 = 0x000400FDu, w1 = blob_len << 16, w2 = (blob_len >> 16) | 0x02000000u;
-                uint32_t wv = i < 4u ? w0 : (i < 8u ? w1 : w2);
-                wv = i < 12u ? wv : (i < 16u ? tot[0] : tot[1]);
-                uint32_t off = i < 12u ? i : (i < 16u ? 112u - 12u + i : 116u - 16u + tot[0] + i);
-                const uint32_t bv = wv >> (8u * (i & 3u));
-                if (i < 20u) lds_st8<0>(f + off, bv);
-                if (ln == 0) A.frame_size[frame0 + h] = flen;
-            }
-            wave_sync();
-            // has the transform wave published the next frame meanwhile? (asked before the flush, needed after it)
-            const uint32_t r0 = peek_counter(&cs.ready[0]), r1 = peek_counter(&cs.ready[1]);
-            const uint32_t have = pend + flen;
-            const uint32_t n16 = have >> 4;
-            const uint4 *src = reinterpret_cast<const uint4 *>(stage);
-            uint4 *dst = reinterpret_cast<uint4 *>(gout + written);
-            for (uint32_t i = ln; i < n16; i += 64) dst[i] = src[i];
-            {
-                const uint32_t a0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r0), a1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r1);
-                ready_early = a0 < a1 ? a0 : a1;
-            }
-            pend = have & 15u;
-            tailb = (ln < (int)pend) ? stage[(n16 << 4) + ln] : 0u;
-            written += (unsigned long long)n16 << 4;
-            wave_sync();
-            STAMP(4);
-#ifdef FLO_STAMPS
-            {
-                const unsigned long long busy = st_last - st_frame0;
-                if (busy > 12000) { st_sum[9] += busy; st_sum[10] += 1; }
-                if (busy > 20000) { st_sum[11] += busy; st_sum[12] += 1; }
-            }
-#endif
-        }
-        if (lane < (int)pend) gout[written + lane] = (uint8_t)tailb;
-        if (lane == 0) A.clip_bytes[clip] = written + pend;
-#ifdef FLO_STAMPS
-        if (A.dbg_stamps && lane == 0)
-        {
-            st_sum[13] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
-                         ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32) | ((unsigned long long)cl << 40);
-            for (int i = 0; i < 14; i++) A.dbg_stamps[((unsigned long long)clip * 2 + 1) * 16 + i] = st_sum[i];
-        }
-#endif
-        fbase += hops;
-        continue;
-    }
-
-
-    // ---------------------------------------------------------------------- transform wave: both channels
-    StereoLds &lds = cs.wl;
-    LossyDevTables T = A.T;
-    T.pack = reinterpret_cast<const float4 *>(lds_raw);
-    const float *pcm = A.pcm + A.clip_off[clip];
-
-    float prev[2] = {0.f, 0.f};   // lanes 0..24: temporal masking state of band `lane`, per channel
-                                  // (merged masking pass: prev[0] alone, channel 1's bands on lanes 32..56)
-    v2f ae[8], ao[8], be[8], bo[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) ae[r] = ao[r] = splat2(0.f);  // pre-roll: 1024 zeros (encoder.rs:177)
-    if (!COEFFS) load_half_fast_2(lane_id_opaque(), pcm, 0, be, bo);   // (opaque: keeps 16 address pairs out of loop-invariant registers)
 #ifdef FLO_MARKS   // diagnostic builds: section markers in the assembly listing (they pin the schedule: never shipped)
 #define FLO_MARK(x) asm volatile("; MARK " x ::: "memory")
 #else
 #define FLO_MARK(x)
 #endif
-#ifdef FLO_STAMPS
-    unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
-#endif
-    auto frame_body = [&](const unsigned h, v2f (&pe)[8], v2f (&po)[8], v2f (&ce)[8], v2f (&co)[8]) __attribute__((always_inline)) {
-        const int ln = lane_id_opaque();
-        FLO_MARK("frame_begin");
-        v2f c[16];
-        if (COEFFS) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 v0 = reinterpret_cast<const float4 *>(A.in_coeffs + ((frame0 + h) * 2 + 0) * 1024 + 16 * ln)[q];
-                const float4 v1 = reinterpret_cast<const float4 *>(A.in_coeffs + ((frame0 + h) * 2 + 1) * 1024 + 16 * ln)[q];
-                c[4 * q] = (v2f){v0.x, v1.x}; c[4 * q + 1] = (v2f){v0.y, v1.y};
-                c[4 * q + 2] = (v2f){v0.z, v1.z}; c[4 * q + 3] = (v2f){v0.w, v1.w};
-            }
-        } else {
-            v2f zr[8], zi[8];
-            fold_2(ln, pe, po, ce, co, zr, zi, T);
-            FLO_MARK("fold_done");
-            STAMP(0);
-            // the older half is dead after the fold: the half-frame after next is loaded into its registers now and
-            // consumed at the top of the next call. Unconditional, also behind the last frame (the batch allocates one
-            // spare half-frame per clip): see lossy_chain_kernel
-            load_half_fast_2(ln, pcm, (long long)(h + 1) * 1024, pe, po);
-            FLO_MARK("prefetch_done");
-            STAMP(1);
-#if (FLO_SKIP & 8) == 0   // FLO_SKIP (diagnostic builds, results invalid): leave a phase out to see what it costs in a counter
-            fft512_2(ln, zr, zi, lds.u.xch4, T);
-#endif
-            FLO_MARK("fft_done");
-            STAMP(2);
-#if (FLO_SKIP & 4) == 0
-            post_rotate_transpose_2(ln, zr, zi, lds.u.coef2, c, T);
-#else
-#pragma unroll
-            for (int e = 0; e < 8; e++) { c[2 * e] = zr[e]; c[2 * e + 1] = zi[e]; }
-#endif
-            FLO_MARK("postrot_done");
-            STAMP(3);
 
-            if (DBG && A.dbg_coeffs) {
-#pragma unroll
-                for (int ch = 0; ch < 2; ch++) {
-                    float *d = A.dbg_coeffs + ((frame0 + h) * 2 + ch) * 1024 + 16 * ln;
-#pragma unroll
-                    for (int e = 0; e < 16; e++) d[e] = ch ? c[e].y : c[e].x;
-                }
-            }
-        }
-        // band statistics, masking level, temporal masking, scale factors (analyse_frame, both channels)
-        float energy1, bmax1;   // channel 0's band b on lane b, channel 1's on lane 32 + b
-#if (FLO_SKIP & 1) == 0
-        band_stats_2<DIRTY>(ln, c, lds.u.a.slot, T, energy1, bmax1);
-#else
-        energy1 = c[0].x + c[5].y;
-        bmax1 = c[1].x + c[7].y;
-#endif
-        FLO_MARK("bandstats_done");
-        STAMP(4);
-        QuantRows qrows;   // in flight under the masking pass
-        quant_rows_load(ln, T, qrows);
-        const uint32_t consumed_early = peek_counter(&cs.consumed);   // the hand-over's usual answer, two phases ahead
-        __builtin_amdgcn_sched_barrier(0);
-        // masking level, temporal step and scale factors of both channels in one pass: channel 0 on lanes 0..24, channel 1
-        // on lanes 32..56 (band_stats_2 leaves every band's totals in both halves)
-        const int bnd = ln & 31, up = ln >> 5;
-        const float rcount = T.pack[kRowLane * 64 + ln].z;   // (the row holds band (lane & 31)'s value on every lane)
-        uint32_t sfw1;
-        {
-            const float a = spread_threshold_2(ln, energy1, rcount, T);
-            const float sl = max_raw(a, prev[0] * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
-            prev[0] = sl;
-            const float tl1 = masking_amplitude(sl, T.smr_thr);
-            const float bm = bmax1;
-            const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
-            sfw1 = sf_word(sfv1);
-            if (bnd < 25) {
-                // (a scalar base + two shift-adds: as base + member offset + two products the address took four instructions)
-                typedef __attribute__((address_space(3))) float lds_f32;
-                const uint32_t ts_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds.u.a.ts);
-                lds_f32 *tp = reinterpret_cast<lds_f32 *>((uintptr_t)(ts_s + 16u * (uint32_t)bnd + 4u * (uint32_t)up));
-                tp[0] = tl1;
-                tp[2] = sfv1;
-            }
-        }
-        wave_sync();
-        FLO_MARK("mask_done");
-        STAMP(5);
-        uint32_t xs[2][8];
-#if (FLO_SKIP & 2) == 0
-        quantise_2(ln, c, lds, T, qrows, xs);
-#else
-#pragma unroll
-        for (int k = 0; k < 8; k++) { xs[0][k] = __float_as_uint(c[2 * k].x) & 0x00010001u; xs[1][k] = __float_as_uint(c[2 * k + 1].y) & 0x00010001u; }
-#endif
-        FLO_MARK("quant_done");
-        STAMP(6);
-        if (DBG && A.dbg_q) {
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++) {
-                uint32_t *dq = reinterpret_cast<uint32_t *>(A.dbg_q + ((frame0 + h) * 2 + ch) * 1024 + 16 * ln);
-#pragma unroll
-                for (int k = 0; k < 8; k++) dq[k] = xs[ch][k];
-            }
-        }
-        if (DBG && A.dbg_sfw && bnd < 25) A.dbg_sfw[((frame0 + h) * 2 + up) * 25 + bnd] = (unsigned short)sfw1;
-        // the packer has taken the previous frame out of the hand-over buffer (usually long ago: see consumed_early)
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)consumed_early) < fbase + h) wait_counter(&cs.consumed, fbase + h);
-#ifdef FLO_STAMPS
-        {
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned long long t_;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
-            const unsigned long long dt = t_ - st_last;
-            if (dt > 1000) { st_sum[9] += dt; st_sum[10] += 1; }
-            if (dt > 5000) { st_sum[11] += dt; st_sum[12] += 1; }
-        }
-#endif
-        STAMP(7);
-#pragma unroll
-        for (int ch = 0; ch < 2; ch++) {
-            // natural order: the lane's 16 integers are 32 contiguous bytes, except that lanes 4..7 of every eight store
-            // their two 16-byte halves the other way round: a 16-byte store instruction then covers all banks with eight
-            // consecutive lanes (at a plain 32-byte stride lanes l and l + 4 would collide); the packer reads accordingly
-            uint4 *dq = reinterpret_cast<uint4 *>(cs.qh[ch]);
-            const int sw = (ln >> 2) & 1;
-            dq[2 * ln + sw] = make_uint4(xs[ch][0], xs[ch][1], xs[ch][2], xs[ch][3]);
-            dq[2 * ln + (sw ^ 1)] = make_uint4(xs[ch][4], xs[ch][5], xs[ch][6], xs[ch][7]);
-        }
-        if (bnd < 25) cs.sfwh[up][bnd] = (uint16_t)sfw1;
-        set_counter(&cs.ready[0], fbase + h + 1);
-        set_counter(&cs.ready[1], fbase + h + 1);
-        FLO_MARK("frame_end");
-        STAMP(8);
-    };
-    for (unsigned h = 0; h < hops; h += 2) {
-        frame_body(h, ae, ao, be, bo);
-        if (h + 1 < hops) frame_body(h + 1, be, bo, ae, ao);
-    }
-#ifdef FLO_STAMPS
-    if (A.dbg_stamps && lane == 0)
-    {   // [13]: where the wave ran (HW_ID, XCC_ID, clip slot): diag/stamps_clips.py groups the records by it
-        st_sum[13] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
-                     ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32) | ((unsigned long long)cl << 40);
-        for (int i = 0; i < 14; i++) { A.dbg_stamps[((unsigned long long)clip * 2) * 16 + i] = st_sum[i]; st_sum[i] = 0; }
-    }
-#endif
-    fbase += hops;
-    }   // next clip
-}
-
-// ---------------------------------------------------------------------------------------------- two waves per clip, the packer quantises
-// The same pair of waves per stereo clip as lossy_chain2x_kernel with the work divided differently: the TRANSFORM wave
-// stops after the masking pass (fold, FFT, post-rotation, band statistics, masking level, scale factors) and the PACKER
-// wave quantises. Twelve waves land round-robin on four SIMDs, so two SIMDs hold (transform, transform, packer) and
-// two hold (transform, packer, packer); with the quantiser in the transform wave the first kind carried 1941 vector
-// instructions per frame round against 1350 and set the launch time. What crosses the waves:
+// ---------------------------------------------------------------------------------------------- two waves per clip
+// Stereo clips. One TRANSFORM wave per clip carries both channels in lock-step: every constant row (window, twiddles, band
+// tables) is read from LDS once per frame for both channels, the PCM comes in as float2 loads (both channels of a
+// sample-frame), every arithmetic instruction of fold, FFT and post-rotation is a packed one, and the two channels are
+// two independent dependency chains inside one instruction stream. It stops after the masking pass (fold, FFT,
+// post-rotation, band statistics, masking level, scale factors); the PACKER wave quantises, serialises and flushes.
+// Twelve waves land round-robin on four SIMDs, so two SIMDs hold (transform, transform, packer) and two hold
+// (transform, packer, packer): with the quantiser in the transform wave (rounds 2 and 3) the first kind carried 1941
+// vector instructions per frame round against 1350 and set the launch time. What crosses the waves:
 //   * the f32 coefficients, which are NOT copied: the packer reads them (one 16-byte read per block of 128 positions, in
 //     the layout its sparse packer wants: no re-dealing of integers either) out of the transposition buffer the
 //     post-rotation left them in, as soon as `coef_ready` says so, and answers `consumed`; the transform wave needs the
-//     buffer again for the first FFT exchange of the NEXT frame, after that frame's fold and prefetch;
-//   * 25 x (threshold amplitude, scale factor) per channel and the scale words, in tables of their own chosen by frame
-//     parity (`ts_ready`): the packer may still be reading frame h - 1's while frame h's are written.
+//     buffer again for the first FFT exchange of the NEXT frame;
+//   * 25 x (threshold amplitude, scale factor) per channel, the scale words and the band-alive ballot, in tables of
+//     their own chosen by frame parity (`ts_ready`): the packer may still be reading frame h - 1's while frame h's are
+//     written.
 // The quantiser's per-position constants (ATH thresholds, band offsets) live in the packer's registers for the whole
-// launch (rows kRowAthN / kRowBoN, read from global memory once): they leave the LDS pack, and so does the i16 hand-over.
+// launch (rows kRowAthN / kRowBoN, read from global memory once): they are not in the LDS pack, and there is no i16
+// hand-over buffer. Same device functions where the work is the same, same bytes as the other forms.
 struct Clip2qLds {
     union {
         float4 xch4[kXch4];      // FFT exchanges
@@ -1149,6 +487,9 @@ struct Clip2qLds {
 static_assert(sizeof(Clip2qLds) % 16 == 0, "clip LDS block keeps 16-byte alignment");
 constexpr int kPackBytesHotT = kPackRowsHotT * 64 * 16;
 
+#ifndef FLO_PSLEEP
+#define FLO_PSLEEP 1
+#endif
 template <bool COEFFS, uint32_t DIRTY, bool DBG>
 __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArgs A, int clips_per_wg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -1170,8 +511,11 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
     // waves 0 .. g-1 are the transform waves, waves g .. 2g-1 the packers
     const int cl = wv % clips_per_wg;
     Clip2qLds &cs = *reinterpret_cast<Clip2qLds *>(lds_raw + kPackBytesHotT + (size_t)cl * sizeof(Clip2qLds));
-    // Persistent workgroups, clips dealt dynamically (see lossy_chain2x_kernel): the packer claims, frame counters run on
-    // across clips. The two roles are two separate loops so that neither's registers are live in the other's code.
+    // Clips are dealt dynamically: the workgroups are persistent (one per CU, the LDS holds no second one) and every
+    // (transform wave, packer wave) pair takes the next unclaimed clip of the batch when it has finished one, so CUs
+    // stay full until the batch runs out whatever the clip lengths. The packer claims (one atomic per clip) and tells
+    // its transform wave through LDS; frame counters run on across clips (fbase), so nothing is ever reset. The two
+    // roles are two separate loops so that neither's registers are live in the other's code.
     uint32_t fbase = 0, seq = 0;
     if (wv >= clips_per_wg) {
         // ------------------------------------------------------------------ packer: quantise, serialise, flush
@@ -1241,7 +585,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
                     for (int q = 0; q < 8; q++) blk[q] = bp[q];
                 }
                 if (!have) {
-                    wait_counter(&cs.coef_ready, g + 1);
+                    wait_counter<FLO_PSLEEP>(&cs.coef_ready, g + 1);
 #pragma unroll
                     for (int k = 0; k < 8; k++) cf[k] = *reinterpret_cast<const lds_v4f *>((uintptr_t)(cf_a + 1152u * (uint32_t)k));
                     set_counter(&cs.consumed, g + 1);   // (behind the reads: a wave's LDS instructions execute in order)
@@ -1250,14 +594,19 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
 #ifdef FLO_STAMPS
                 const unsigned long long st_frame0 = st_last;
 #endif
-                wait_counter(&cs.ts_ready, g + 1);
+                wait_counter<FLO_PSLEEP>(&cs.ts_ready, g + 1);
                 STAMP(5);
                 const uint32_t par = g & 1u;
                 const uint32_t sfw_both = cs.sfwh[par][ln >> 5][ln & 31];   // scale words: lanes 0..24 left, 32..56 right
                 const uint32_t alive = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cs.alive[par][0] | cs.alive[par][1]));
                 uint32_t xd[2][8];   // xd[ch][k] = positions 128 k + 2 lane (low half) and + 1
+#if (FLO_SKIP & 64) == 0
                 if (par) quantise_nat<512>(cf, ts_a, athn, alive, blk, xd);
                 else quantise_nat<0>(cf, ts_a, athn, alive, blk, xd);
+#else
+#pragma unroll
+                for (int q = 0; q < 8; q++) { xd[0][q] = __float_as_uint(cf[q].x) & alive & 0x00010001u; xd[1][q] = __float_as_uint(cf[q].y) & blk[q] & 0x00010001u; }
+#endif
                 have = false;   // cf is free again
                 take_next();
                 STAMP(1);
@@ -1284,8 +633,16 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
                 // runs or a run longer than 255, q >= 0.99 in practice - the general form; same bytes (tests compare them)
 #pragma unroll
                 for (int ch = 0; ch < 2; ch++) {
+#if (FLO_SKIP & 32) == 0
                     uint32_t t = sparse_item_pack(ln, xd[ch], f_a + pos + 4u, tab_a);
+#ifdef FLO_STAMPS
+                    if (t == kSparseFallback) st_sum[6] += 1;   // channel-frames the item form declined
+#endif
                     if (t == kSparseFallback) t = sparse_block_pack(ln, xd[ch], f_a + pos + 4u, tab_a);
+#else
+                    uint32_t t = 3u + ((xd[ch][0] | xd[ch][3]) & 1u);
+                    FLO_KEEP(xd[ch][1]); FLO_KEEP(xd[ch][2]); FLO_KEEP(xd[ch][4]); FLO_KEEP(xd[ch][5]); FLO_KEEP(xd[ch][6]); FLO_KEEP(xd[ch][7]);
+#endif
                     if (t == kSparseFallback) {   // uniform: dense frame (many runs, a run longer than 255)
                         // the general form wants the lane's 16 contiguous values: one trip through the (still unused) tail of
                         // the staging buffer re-deals the dwords
@@ -1372,6 +729,16 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
 #endif
     LossyDevTables T = A.T;
     T.pack = reinterpret_cast<const float4 *>(lds_raw);
+#ifndef FLO_SO_LDS
+    // the slot area belongs to band statistics alone in this form: its zero slot is written once and the lane's twelve
+    // gather addresses stay in registers (the wave has them to spare now that the quantiser lives in the packer)
+    uint32_t so_pre[12];
+    band_stats_2_prepare(lane, cs.slot, A.T.pack, so_pre);
+    constexpr bool kSoPre = true;
+#else
+    const uint32_t *so_pre = nullptr;
+    constexpr bool kSoPre = false;
+#endif
     for (;;) {
         wait_counter(&cs.clip_seq, ++seq);
         const unsigned clip = (unsigned)__builtin_amdgcn_readfirstlane((int)cs.clip_cur);
@@ -1465,12 +832,21 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
                 STAMP(1);
                 if ((uint32_t)__builtin_amdgcn_readfirstlane((int)consumed_early) < g) wait_counter(&cs.consumed, g);
                 STAMP(7);
+#if (FLO_SKIP & 8) == 0   // FLO_SKIP (diagnostic builds, results invalid): leave a phase out to see what it costs
                 fft512_2(ln, zr, zi, cs.u.xch4, T, [&]() __attribute__((always_inline)) {
                     if (h > 0) mask_publish(ln, g - 1u, h - 1u, pend_e, pend_m, rcount, sd0, sd1);   // uniform
                 });
+#else
+                if (h > 0) mask_publish(ln, g - 1u, h - 1u, pend_e, pend_m, rcount, sd0, sd1);
+#endif
                 FLO_MARK("fft_done");
                 STAMP(2);
+#if (FLO_SKIP & 4) == 0
                 post_rotate_transpose_2(ln, zr, zi, cs.u.coef2, c, T);
+#else
+#pragma unroll
+                for (int e = 0; e < 8; e++) { c[2 * e] = zr[e]; c[2 * e + 1] = zi[e]; }
+#endif
                 FLO_MARK("postrot_done");
                 STAMP(3);
                 if (DBG && A.dbg_coeffs) {
@@ -1485,7 +861,12 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
             set_counter(&cs.coef_ready, g + 1);
             // band statistics (both channels): channel 0's band b on lane b, channel 1's on lane 32 + b
             float energy1, bmax1;
-            band_stats_2<DIRTY>(ln, c, cs.slot, T, energy1, bmax1);
+#if (FLO_SKIP & 1) == 0
+            band_stats_2<DIRTY, kSoPre>(ln, c, cs.slot, T, energy1, bmax1, so_pre);
+#else
+            energy1 = c[0].x + c[5].y;
+            bmax1 = c[1].x + c[7].y;
+#endif
             FLO_MARK("bandstats_done");
             STAMP(4);
             if (COEFFS) {
@@ -1493,7 +874,12 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
             } else {
                 pend_e = energy1, pend_m = bmax1;
                 // the next frame's fold
+#if (FLO_SKIP & 128) == 0
                 fold_2(ln, fe, fo, ne, no, zr, zi, T);
+#else
+#pragma unroll
+                for (int r = 0; r < 8; r++) { zr[r] = fe[r] + ne[r]; zi[r] = fo[r] - no[r]; }
+#endif
             }
             FLO_MARK("frame_end");
             STAMP(5);
@@ -1577,7 +963,7 @@ __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
 }
 
 // Stereo frames, shipped quantiser, PCM input: the frame-parallel passes built from the lock-step stereo device
-// functions of lossy_chain2x_kernel (packed f32 transform of both channels, both channels' masking in one pass, ballot
+// functions of lossy_chain2q_kernel (packed f32 transform of both channels, both channels' masking in one pass, ballot
 // packer) - one wave does a frame's transform AND packing here. Same bytes as every other form (tests compare them).
 template <int PASS>
 __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
@@ -2078,47 +1464,6 @@ static int launch_chain_t(const LossyArgs &A, hipStream_t s) {
     return 0;
 }
 
-// clips per workgroup of the three-wave form: 15 waves (960 threads) and 160 KiB of LDS hold five
-int chain3_clips_per_wg(int n_clips) {
-    int g = (n_clips + 255) / 256;
-    const int gmax = (int)((160 * 1024 - kPackBytes) / sizeof(Clip3Lds));
-    if (g > gmax) g = gmax;
-    if (g > 5) g = 5;
-    return g < 1 ? 1 : g;
-}
-template <bool EXACT>
-static int launch_chain3_t(const LossyArgs &A, hipStream_t s) {
-    const int g = chain3_clips_per_wg(A.n_clips);
-    const size_t lds = kPackBytes + (size_t)g * sizeof(Clip3Lds);
-    if (int rc = allow_big_lds(reinterpret_cast<const void *>(&lossy_chain3_kernel<EXACT>))) return rc;
-    const unsigned wgs = (unsigned)((A.n_clips + g - 1) / g);
-    hipLaunchKernelGGL((lossy_chain3_kernel<EXACT>), dim3(wgs), dim3(192 * g), lds, s, A, g);
-    FLO_LAUNCH_CHECK();
-    return 0;
-}
-// clips per workgroup of the two-wave (lock-step stereo) form
-int chain2x_clips_per_wg(int n_clips) {
-    int g = (n_clips + 255) / 256;
-    const int gmax = (int)((160 * 1024 - kPackBytesHot) / sizeof(Clip2xLds));
-    if (g > gmax) g = gmax;
-    if (g > FLO_C2X_THREADS / 128) g = FLO_C2X_THREADS / 128;   // twelve waves: three per SIMD (up to 168 registers each)
-    return g < 1 ? 1 : g;
-}
-template <bool COEFFS, uint32_t DIRTY, bool DBG>
-static int launch_chain2x_t(const LossyArgs &A, hipStream_t s) {
-    int g = chain2x_clips_per_wg(A.n_clips);
-    if (const char *e = getenv("FLO_CHAIN2X_CLIPS")) {   // diagnostic: clips per workgroup
-        const int v = atoi(e);
-        if (v >= 1 && v <= FLO_C2X_THREADS / 128) g = v;
-    }
-    const size_t lds = kPackBytesHot + (size_t)g * sizeof(Clip2xLds);
-    if (int rc = allow_big_lds(reinterpret_cast<const void *>(&lossy_chain2x_kernel<COEFFS, DIRTY, DBG>))) return rc;
-    unsigned wgs = (unsigned)((A.n_clips + g - 1) / g);
-    if (A.n_cus > 0 && wgs > (unsigned)A.n_cus) wgs = (unsigned)A.n_cus;   // persistent: one workgroup per CU, clips dealt dynamically
-    hipLaunchKernelGGL((lossy_chain2x_kernel<COEFFS, DIRTY, DBG>), dim3(wgs), dim3(128 * g), lds, s, A, g);
-    FLO_LAUNCH_CHECK();
-    return 0;
-}
 // clips per workgroup of the two-wave form whose packer quantises
 int chain2q_clips_per_wg(int n_clips) {
     int g = (n_clips + 255) / 256;
@@ -2148,18 +1493,6 @@ int launch_lossy_chain2q(const LossyArgs &A, hipStream_t s) {
     if (A.dbg_coeffs || A.dbg_q || A.dbg_sfw) return launch_chain2q_t<false, 0xFFFFu, true>(A, s);
     return (A.T.dirty | 0x8000u) == kDirty44k ? launch_chain2q_t<false, kDirty44k, false>(A, s) : launch_chain2q_t<false, 0xFFFFu, false>(A, s);
 }
-int launch_lossy_chain2x(const LossyArgs &A, hipStream_t s) {
-    if (A.nch != 2 || A.exact) return -1;   // the exact-threshold test yardstick lives in the other forms
-    if (A.in_coeffs) return launch_chain2x_t<true, 0xFFFFu, true>(A, s);
-    if (A.dbg_coeffs || A.dbg_q || A.dbg_sfw) return launch_chain2x_t<false, 0xFFFFu, true>(A, s);
-    return (A.T.dirty | 0x8000u) == kDirty44k ? launch_chain2x_t<false, kDirty44k, false>(A, s) : launch_chain2x_t<false, 0xFFFFu, false>(A, s);
-}
-
-int launch_lossy_chain3(const LossyArgs &A, hipStream_t s) {
-    if (A.nch != 2) return -1;
-    return A.exact ? launch_chain3_t<true>(A, s) : launch_chain3_t<false>(A, s);
-}
-
 int launch_lossy_chain(const LossyArgs &A, hipStream_t s) {
     if (A.nch == 1) return A.exact ? launch_chain_t<1, true>(A, s) : launch_chain_t<1, false>(A, s);
     if (A.nch == 2) return A.exact ? launch_chain_t<2, true>(A, s) : launch_chain_t<2, false>(A, s);

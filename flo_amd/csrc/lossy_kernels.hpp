@@ -43,9 +43,7 @@ struct LossyArgs {
 };
 
 int launch_lossy_chain(const LossyArgs &A, hipStream_t s);
-int launch_lossy_chain3(const LossyArgs &A, hipStream_t s);
-int launch_lossy_chain2x(const LossyArgs &A, hipStream_t s);  // stereo only: one lock-step transform wave + one packer wave per clip
-int launch_lossy_chain2q(const LossyArgs &A, hipStream_t s);  // the same pair of waves, the quantiser in the packer wave
+int launch_lossy_chain2q(const LossyArgs &A, hipStream_t s);  // stereo only: one lock-step transform wave + one quantiser-and-packer wave per clip
 int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s);
 // bytes reserved per frame in the frame-parallel form: header + scale words + every channel's largest sparse blob
 inline unsigned int lossy_slot_bytes(int nch) {

@@ -113,10 +113,10 @@ int flo_batch_upload(flo_batch *b, size_t clip, const float *pcm);
  * clip ids start at clip_id0 so that ranks of a sharded job generate disjoint parts of one corpus */
 int flo_batch_fill_synthetic(flo_batch *b, uint32_t seed, uint64_t clip_id0);
 /* launch the encode kernels on the ctx stream (asynchronous). which = 0: auto, 1: clip-chain kernel with one wave
- * per channel, 2: frame-parallel kernels, 3: clip-chain kernel with two channel waves + one packer wave per stereo
- * clip, 4: clip-chain kernel with one transform wave that carries both channels in lock-step (packed f32 arithmetic)
- * + one packer wave per stereo clip, persistent workgroups that deal the clips dynamically: the form auto picks for
- * stereo batches (lossy only; all forms produce identical bytes; 3 and 4 fall back to 1 for mono) */
+ * per channel, 2: frame-parallel kernels, 5: clip-chain kernel with one transform wave that carries both channels in
+ * lock-step (packed f32 arithmetic) + one quantiser-and-packer wave per stereo clip, persistent workgroups that deal
+ * the clips dynamically: the form auto picks for stereo batches; 3 and 4 (stereo chain forms of earlier rounds,
+ * retired) mean 5 (lossy only; all forms produce identical bytes; 5 falls back to 1 for mono) */
 int flo_batch_encode(flo_batch *b, int which);
 int flo_batch_sync(flo_batch *b);
 /* after sync: total compressed DATA bytes of the batch, and of one clip */
@@ -228,7 +228,7 @@ int flo_ctx_profile_enable(flo_ctx *ctx, int on);
 /* sum and count of bracketed launches of `kernel` since the last reset (call after a sync) */
 int flo_ctx_profile_query(flo_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 int flo_ctx_profile_reset(flo_ctx *ctx);
-/* test hook: force the lossy kernel form (0 auto, 1 .. 4 as in flo_batch_encode) */
+/* test hook: force the lossy kernel form (0 auto, 1 .. 5 as in flo_batch_encode) */
 int flo_ctx_force_path(flo_ctx *ctx, int which);
 /* stream handle (hipStream_t) of the context, for callers that enqueue their own work around the encode */
 void *flo_ctx_stream(flo_ctx *ctx);

@@ -267,7 +267,7 @@ def test_full_size_configs_round_trip_on_the_device(ctx, n_clips, seconds, q):
         return buf[: offs[-1]], nbytes
 
     first, nbytes = packed(0)
-    for form in (1, 2, 3, 4, 5, 0, 5, 4, 3, 1):    # two-wave chain, frame-parallel, three-wave chain, the two lock-step stereo chains, and again (idempotence)
+    for form in (1, 2, 5, 0, 5, 1):    # one-wave-per-channel chain, frame-parallel, lock-step stereo chain, and again (idempotence)
         other, nb = packed(form)
         assert nb == nbytes and torch.equal(first, other), form
     assert 0.02 * n_sf * ch * n_clips < nbytes < 4.0 * n_sf * ch * n_clips * 0.5   # 2 % .. 50 % of the f32 input

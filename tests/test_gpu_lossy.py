@@ -150,7 +150,7 @@ def test_quantiser_fed_oracle_spectra(ctx, q, exact):
     # "exact" adds the reference's dB-domain re-check next to the threshold. Both meet the same bound.
     pcm = signals.music_like(44100, 30000, 2, seed=3)
     o = O.lossy_analyze(pcm, 44100, 2, q)
-    for path in ((0,) if exact else (0, 4, 5)):   # 5 = the benchmarked form: the quantiser runs in the packer wave, natural layout
+    for path in ((0,) if exact else (0, 5)):   # 5 = the benchmarked form: the quantiser runs in the packer wave, natural layout
         ctx.force_path(path)
         g = ctx.lossy_quantize(o["coeffs"], 44100, q, exact=exact)
         ctx.force_path(0)
@@ -215,7 +215,7 @@ def test_analyze_parity(ctx, ch, q):
     pcm = signals.music_like(44100, 40000, ch, seed=10 + ch)
     o = O.lossy_analyze(pcm, 44100, ch, q)
     first = None
-    for path in (1, 2, 3, 4, 5):      # 3, 4 and 5 are stereo forms (mono falls back to 1)
+    for path in (1, 2, 5):      # 5 is the stereo chain form (mono falls back to 1)
         ctx.force_path(path)
         g = ctx.lossy_analyze(pcm, 44100, ch, q)
         compare_lossy_stage(g, o, 44100, tag=f"path{path}")
@@ -233,9 +233,8 @@ def test_other_sample_rates(ctx, sr):
     pcm = signals.music_like(sr, 20000, 2, seed=sr)
     o = O.lossy_analyze(pcm, sr, 2, 0.55)
     compare_lossy_stage(ctx.lossy_analyze(pcm, sr, 2, 0.55), o, sr)
-    for path in (4, 5):        # the lock-step stereo forms have their own band-statistics code (5: and the quantiser in the packer wave, natural layout): other band tables too
-        ctx.force_path(path)
-        compare_lossy_stage(ctx.lossy_analyze(pcm, sr, 2, 0.55), o, sr, tag=f"path{path}")
+    ctx.force_path(5)          # the lock-step stereo form has its own band-statistics code and quantises in the packer wave (natural layout): other band tables too
+    compare_lossy_stage(ctx.lossy_analyze(pcm, sr, 2, 0.55), o, sr, tag="path5")
     ctx.force_path(0)
     # the whole drop-in call and the decode at this rate (from 128 kHz up band 24 spans more than 48 lane segments)
     flo = ctx.encode_lossy(pcm, sr, 2, 0.55)
@@ -252,37 +251,28 @@ def test_chain_and_frame_parallel_forms_give_identical_files(ctx):
     a = ctx.encode_lossy(pcm, 44100, 2, 0.55)
     ctx.force_path(2)
     b = ctx.encode_lossy(pcm, 44100, 2, 0.55)
-    ctx.force_path(3)
-    c = ctx.encode_lossy(pcm, 44100, 2, 0.55)
-    ctx.force_path(4)
-    d = ctx.encode_lossy(pcm, 44100, 2, 0.55)
     ctx.force_path(5)
-    e = ctx.encode_lossy(pcm, 44100, 2, 0.55)
+    c = ctx.encode_lossy(pcm, 44100, 2, 0.55)
     ctx.force_path(0)
     assert a == b
     assert a == c
-    assert a == d
-    assert a == e
 
 
 @pytest.mark.parametrize("q", [0.0, 0.55, 1.0])
-def test_three_wave_pipeline_matches_chain_on_a_ragged_batch(ctx, q):
-    # clips of different lengths (and one empty) in one launch: the packer wave and the two channel waves of every
-    # clip run their own frame counts; bytes must equal the two-wave chain form
+def test_lock_step_pipeline_matches_chain_on_a_ragged_batch(ctx, q):
+    # clips of different lengths (and one empty) in one launch: the transform wave and the packer wave of every
+    # clip run their own frame counts; bytes must equal the one-wave-per-channel chain form
     lens = [0, 1, 1023, 1024, 5000, 44100, 70001, 3 * 1024]
     clips = [signals.music_like(44100, n, 2, seed=40 + i) for i, n in enumerate(lens)]
     ctx.force_path(1)
     a = ctx.encode_batch(1, clips, 44100, 2, q)
-    ctx.force_path(3)
+    ctx.force_path(5)     # lock-step stereo transform wave + quantiser-and-packer wave, persistent workgroups dealing the clips dynamically
     b = ctx.encode_batch(1, clips, 44100, 2, q)
-    ctx.force_path(4)     # lock-step stereo transform wave, persistent workgroups dealing the clips dynamically
+    ctx.force_path(2)
     c = ctx.encode_batch(1, clips, 44100, 2, q)
-    ctx.force_path(5)     # the same pair of waves, the quantiser in the packer wave
-    d = ctx.encode_batch(1, clips, 44100, 2, q)
     ctx.force_path(0)
     assert a == b
     assert a == c
-    assert a == d
 
 
 @pytest.mark.parametrize("ch", [1, 2])
@@ -331,7 +321,7 @@ def test_near_goldens_reference_made_files(ctx, name, q, src):
 def test_edge_lengths(ctx, n, ch):
     pcm = signals.fast_noise(n * ch, 7, 0.4)
     o = O.encode_lossy(pcm, 44100, ch, 0.55)
-    for path in (0, 1, 2, 3, 4, 5):     # 0 = what an encode call picks by itself, 5 = the benchmarked lock-step form
+    for path in (0, 1, 2, 5):     # 0 = what an encode call picks by itself, 5 = the benchmarked lock-step form
         ctx.force_path(path)
         g = ctx.encode_lossy(pcm, 44100, ch, 0.55)
         fg, _ = same_structure(g, o)
@@ -549,7 +539,7 @@ def test_kernel_forms_agree_on_loud_and_lopsided_stereo(ctx, amp):
             x[::2] = 0.0
         clips.append(x.astype(np.float32))
     outs = {}
-    for form in (4, 1, 2, 3, 5):
+    for form in (5, 1, 2):
         b = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [c.size for c in clips], sr, ch, 0.55)
         for i, c in enumerate(clips):
             b.upload(i, c)
@@ -557,5 +547,5 @@ def test_kernel_forms_agree_on_loud_and_lopsided_stereo(ctx, amp):
         b.sync()
         outs[form] = [b.fetch(i) for i in range(len(clips))]
         b.close()
-    for form in (1, 2, 3, 5):
-        assert outs[form] == outs[4], form
+    for form in (1, 2):
+        assert outs[form] == outs[5], form
