@@ -91,7 +91,9 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=10000)
     ap.add_argument("--clip-seconds", type=float, default=10.0)
     ap.add_argument("--quality", type=float, default=0.55)
-    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 two-wave chain kernel, 2 frame-parallel kernels, 3 three-wave chain kernel, 4 lock-step stereo chain kernel")
+    ap.add_argument("--path", type=int, default=0, help="0 auto, 1 chain kernel with one wave per channel, 2 frame-parallel kernels, 5 lock-step stereo chain kernel")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the exchange legs (gather, strong-scaling shard, table mode) with a one-rank communicator when N = 1 (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-clip", action="store_true")
     ap.add_argument("--no-lossless", action="store_true")
@@ -121,23 +123,41 @@ def main():
     batch.fill_synthetic(seed=0xF10A0D10, clip_id0=rank * args.clips_per_gpu)
     samples_per_step_rank = n_il * args.clips_per_gpu
 
+    def all_ok(flag):
+        """True only if `flag` holds on every rank (every rank must take the same branch)"""
+        if dist is None:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    def all_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     gather, gather_error = None, None
-    if world > 1:
+    exchanging = world > 1 or args.force_exchange
+    if exchanging:
         # the exchange step lives behind the C ABI (flo_dist_*: RCCL directly, own stream, double-buffered); torch's
         # process group only carries the 128-byte rendezvous token from rank 0 to the others
         from flo_amd.dist import ID_BYTES, NativeGather, unique_id
-        tok = torch.zeros(ID_BYTES, dtype=torch.uint8, device=f"cuda:{local_rank}")
-        if rank == 0:
-            tok.copy_(torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8))
-        dist.broadcast(tok, src=0)
+        if dist is not None:
+            tok = torch.zeros(ID_BYTES, dtype=torch.uint8, device=f"cuda:{local_rank}")
+            if rank == 0:
+                tok.copy_(torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8))
+            dist.broadcast(tok, src=0)
+            tok_bytes = bytes(tok.cpu().numpy().tobytes())
+        else:
+            tok_bytes = unique_id()
         try:
-            gather = NativeGather(ctx, bytes(tok.cpu().numpy().tobytes()), rank, world, 0)
+            gather = NativeGather(ctx, tok_bytes, rank, world, 0)
         except Exception as e:   # noqa: BLE001 - reported in the JSON line, never silent
             gather_error = f"rank {rank}: {e}"
-        # every rank must take the same branch: if the communicator failed anywhere, nobody gathers (and the line says so)
-        ok = torch.tensor([1 if gather is not None else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
+        # if the communicator failed anywhere, nobody gathers (and the line says so)
+        if not all_ok(gather is not None):
             gather = None
             gather_error = gather_error or "the RCCL communicator of flo_dist_create failed on another rank"
             print(f"[bench] exchange step disabled: {gather_error}", file=sys.stderr)
@@ -167,7 +187,11 @@ def main():
             mine = [small.fetch(i) for i in range(8)]
             crc = torch.tensor([zlib.crc32(b"".join(mine)), sum(len(f) for f in mine)], dtype=torch.int64, device=f"cuda:{local_rank}")
             crcs = torch.zeros(2 * world, dtype=torch.int64, device=f"cuda:{local_rank}")
-            dist.all_gather_into_tensor(crcs, crc)
+            if dist is not None:
+                dist.all_gather_into_tensor(crcs, crc)
+            else:
+                crcs.copy_(crc)
+            check_ok = True
             if rank == 0:
                 import ctypes
                 hip = ctypes.CDLL("libamdhip64.so")
@@ -187,13 +211,25 @@ def main():
                     ok = ok and len(files) == 8 and zlib.crc32(b"".join(files)) == int(crcs[2 * r]) and sum(map(len, files)) == int(crcs[2 * r + 1])
                 exchange_check = ("every rank's files arrived byte for byte (8 clips per rank, 3 steps, CRC32 against the rank's own fetch)"
                                   if ok else "MISMATCH: gathered files differ from what the ranks encoded")
+                check_ok = ok
                 if not ok:
                     print("[bench] exchange self-check FAILED: gathered files differ from what the ranks encoded", file=sys.stderr)
             small.close()
-        except Exception as e:   # noqa: BLE001 - the self-check must never take the timed run down with it
+        except Exception as e:   # noqa: BLE001 - reported, and fatal below
+            check_ok = False
             exchange_check = f"self-check raised {type(e).__name__}: {e}"
             print(f"[bench] {exchange_check}", file=sys.stderr)
         wd.cancel()
+        # A gather that does not deliver the ranks' bytes must not produce a scaling number: every rank learns of the
+        # failure, rank 0 prints a line WITHOUT a value, and every rank exits non-zero.
+        if not all_ok(check_ok):
+            if rank == 0:
+                print(json.dumps({"metric": "Msamples/s encoded (44.1k stereo, q=high)", "value": None, "unit": "Msamples/s",
+                                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                                  "error": "exchange self-check failed: " + (exchange_check or "a rank raised; see stderr"),
+                                  "exchange_detail": {"self_check": exchange_check or "failed on another rank", "valid": False}}))
+            sys.stdout.flush()
+            os._exit(4)
 
     def step(with_gather=True):
         batch.encode(args.path)
@@ -219,10 +255,7 @@ def main():
         for _ in range(args.steps):
             step(False)
         barrier()
-        encode_only_dt = time.perf_counter() - t0
-        t = torch.tensor([encode_only_dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        encode_only_dt = float(t.item())
+        encode_only_dt = all_max(time.perf_counter() - t0)
     ctx.profile_reset()
     ctx.profile_enable(True)
     barrier()
@@ -234,10 +267,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = all_max(dt)
 
     # the dominant kernel is whichever chain form ran (auto picks the three-wave pipeline for stereo batches)
     kname, k_ms, k_n = "lossy_frames", 0.0, 0
@@ -251,6 +281,69 @@ def main():
     if gather is not None and rank == 0:
         _, g_offs, g_sizes = gather.result()
         gathered = [int(x) for x in g_sizes]
+
+    strong, table_leg = None, None
+    if gather is not None:
+        from flo_amd.dist import contiguous_shard
+        # --- BASELINE configs[3] read literally: ONE corpus of clips_per_gpu clips sharded across the ranks (strong
+        # scaling), every step = encode of the rank's shard + the ONE gather of the finished files to rank 0
+        c0, c1 = contiguous_shard(args.clips_per_gpu, rank, world)
+        sb = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [n_il] * (c1 - c0), sr, ch, args.quality)
+        sb.fill_synthetic(seed=0xF10A0D10, clip_id0=c0)
+
+        def sstep(with_gather):
+            sb.encode(args.path)
+            sb.sync()
+            if with_gather:
+                gather.submit(sb)
+        for _ in range(max(1, args.warmup)):
+            sstep(True)
+        gather.flush()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sstep(False)
+        barrier()
+        s_enc = all_max(time.perf_counter() - t0)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sstep(True)
+        gather.flush()
+        barrier()
+        s_all = all_max(time.perf_counter() - t0)
+        s_total = n_il * args.clips_per_gpu * args.steps
+        strong = {"workload": f"ONE corpus of {args.clips_per_gpu} x {args.clip_seconds:g} s clips sharded over {world} rank(s) "
+                              f"({c1 - c0} on rank 0), encode + one gather of the finished files per step",
+                  "scaling": "strong", "value": round(s_total / s_all / 1e6, 1), "unit": "Msamples/s",
+                  "ms_per_step": round(s_all / args.steps * 1e3, 4),
+                  "encode_only": {"value": round(s_total / s_enc / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(s_enc / args.steps * 1e3, 4)}}
+        if rank == 0:
+            strong["bytes_per_rank_per_step"] = [int(x) for x in gather.result()[2]]
+        sb.close()
+        # --- second exchange mode, beside the gather and never instead of it: the files stay on their ranks and only the
+        # (size, offset, CRC32) table is all-gathered - what the encode scales to when the root's links are not in the way
+        def tstep():
+            batch.encode(args.path)
+            batch.sync()
+            gather.table_submit(batch, args.clips_per_gpu)
+        tstep()
+        gather.table_flush()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tstep()
+        gather.table_flush()
+        barrier()
+        t_all = all_max(time.perf_counter() - t0)
+        tab = gather.table_result()
+        table_leg = {"workload": "the weak-scaling workload (clips_per_gpu clips on every rank); files stay sharded, one ncclAllGather of "
+                                 "24 bytes per clip names every file (owner, offset, size, CRC32)",
+                     "scaling": "weak", "value": round(samples_per_step_rank * world * args.steps / t_all / 1e6, 1), "unit": "Msamples/s",
+                     "ms_per_step": round(t_all / args.steps * 1e3, 4),
+                     "table_bytes_per_rank_per_step": 8 * (1 + 3 * args.clips_per_gpu),
+                     "files_named": sum(len(t[0]) for t in tab),
+                     "bytes_named": sum(sum(t[0]) for t in tab)}
 
     if rank != 0:
         if dist is not None:
@@ -273,7 +366,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "realtime_factor": round(value * 1e6 / (sr * ch), 1),
-        "exchange": ("none (one rank)" if world == 1 else
+        "exchange": ("none (one rank)" if not exchanging else
                      ("every rank's finished files gathered to rank 0 each step: flo_dist_* (ncclAllGather of sizes + "
                       "grouped ncclSend/ncclRecv on its own stream, overlapping the next encode), inside the timed region"
                       if gather is not None else f"DISABLED, files stayed on their ranks: {gather_error}")),
@@ -287,14 +380,17 @@ def main():
             "compressed_bytes_per_gpu": data_bytes,
         },
     }
-    if world > 1:
-        ex = {"reserved_cus": int(os.environ.get("FLO_RESERVE_CUS", "8")) if gather is not None else 0,
-              "self_check": exchange_check}
+    if exchanging:
+        ex = {"reserved_cus": ctx.reserved_cus(), "self_check": exchange_check, "valid": gather is not None}
+        if strong is not None:
+            ex["strong_" + str(args.clips_per_gpu)] = strong
+        if table_leg is not None:
+            ex["table_exchange"] = table_leg
         if gather is not None and encode_only_dt is not None:
             enc_ms = encode_only_dt / args.steps * 1e3
             into_root = sum(gathered[r] for r in range(world) if r != 0)
             link_gbs = 77.0     # one xGMI link per direction, nominal (each peer has ONE link to the root)
-            t_link_ms = max(gathered[r] for r in range(world) if r != 0) / (link_gbs * 1e9) * 1e3
+            t_link_ms = max([gathered[r] for r in range(world) if r != 0] or [0]) / (link_gbs * 1e9) * 1e3
             ex.update({
                 "encode_only": {"value": round(total_samples / args.steps * args.steps / encode_only_dt / 1e6, 1), "unit": "Msamples/s",
                                 "ms_per_step": round(enc_ms, 4), "note": "the same K steps without flo_dist_gather_submit"},

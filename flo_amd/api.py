@@ -115,7 +115,12 @@ class Context:
         """compute units the persistent encode kernels leave free (for RCCL's kernels when ranks exchange files)"""
         self._chk(self._L.flo_ctx_reserve_cus(self._h, n))
 
+    def reserved_cus(self) -> int:
+        """compute units the persistent encode kernels currently leave free"""
+        return int(self._L.flo_ctx_reserved_cus(self._h))
+
     # -- one clip ---------------------------------------------------------------------------------------
+
     def encode_lossy(self, samples, sample_rate, channels, quality, metadata=b"") -> bytes:
         p = _f32(samples)
         out, n = C.c_void_p(), C.c_size_t()

@@ -376,4 +376,17 @@ int launch_finish_files(FinishArgs A, hipStream_t s) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+__global__ void table_crcs_kernel(const uint8_t *base, unsigned long long *row, unsigned long long n, unsigned long long max_clips) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *p = base + row[1 + max_clips + i] + 26;   // the header's data_crc32 (writer.rs:150), any alignment
+    row[1 + 2 * max_clips + i] = (unsigned long long)p[0] | ((unsigned long long)p[1] << 8) | ((unsigned long long)p[2] << 16) | ((unsigned long long)p[3] << 24);
+}
+int launch_table_crcs(const uint8_t *base, unsigned long long *row, unsigned long long n, unsigned long long max_clips, hipStream_t s) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(table_crcs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, base, row, n, max_clips);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 }  // namespace flo

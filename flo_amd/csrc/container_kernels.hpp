@@ -34,6 +34,10 @@ struct FinishArgs {
 };
 
 int launch_finish_files(FinishArgs A, hipStream_t s);
+// Location table of a batch's finished files (flo_dist_table_*): row = [0] n | [1 .. max] sizes | [1 + max .. 2 max] offsets
+// | [1 + 2 max .. 3 max] CRC32 of DATA. Sizes and offsets are in the row already; this fills the CRC column from the
+// headers of the files at base + offset (byte 26).
+int launch_table_crcs(const uint8_t *base, unsigned long long *row, unsigned long long n, unsigned long long max_clips, hipStream_t s);
 // slices per clip so that about two thousand workgroups run; at most 128, or 512 for the few-long-clips case whose
 // finish_files_kernel runs 1024 threads (one per slice register)
 inline unsigned finish_parts_for(size_t n_clips) {

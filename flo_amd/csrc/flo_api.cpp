@@ -1821,10 +1821,22 @@ struct RcclBackend {
     }
 };
 
+// Second exchange mode (flo_dist_table_*): the files stay where they were made, one ncclAllGather tells every rank where
+// each file of every rank lies (offset in its owner's device buffer), how long it is and the CRC32 of its DATA chunk.
+struct TableSlot {
+    uint64_t *h_mine = nullptr, *d_mine = nullptr, *d_all = nullptr, *h_all = nullptr;   // pinned / device rows
+    size_t words = 0;                 // capacity of one row, in u64
+    hipEvent_t done = nullptr;
+    bool used = false;
+};
 struct flo_dist {
     flo_ctx *ctx = nullptr;
     RcclBackend be;
     flo::DistEngine<RcclBackend> eng;
+    TableSlot tab[2];
+    uint64_t tab_steps = 0;
+    size_t tab_max = 0;               // max_clips of the last submit
+    bool defaulted_reserve = false;   // flo_dist_create set the context's CU reservation (and flo_dist_destroy takes it back)
 };
 
 extern "C" int flo_dist_unique_id(uint8_t *id) {
@@ -1856,8 +1868,16 @@ extern "C" void flo_dist_destroy(flo_dist *d) {
         if (be.ev_sizes[s]) hipEventDestroy(be.ev_sizes[s]);
         if (be.ev_moved[s]) hipEventDestroy(be.ev_moved[s]);
     }
+    for (auto &t : d->tab) {
+        if (t.h_mine) hipHostFree(t.h_mine);
+        if (t.h_all) hipHostFree(t.h_all);
+        if (t.d_mine) hipFree(t.d_mine);
+        if (t.d_all) hipFree(t.d_all);
+        if (t.done) hipEventDestroy(t.done);
+    }
     if (be.comm) ncclCommDestroy(be.comm);
     if (be.cs) hipStreamDestroy(be.cs);
+    if (d->defaulted_reserve) d->ctx->reserve_cus = -1;   // later single-GPU encodes on this context get every CU back
     delete d;
 }
 
@@ -1891,8 +1911,77 @@ extern "C" int flo_dist_create(flo_ctx *c, const uint8_t *id, int rank, int worl
     // RCCL's send / receive are kernels: with more than one rank the persistent chain kernel leaves a few compute units
     // free for them, or the transfer of step k could not start before the encode of step k + 1 has ended
     // (flo_ctx_reserve_cus; an explicit setting or FLO_RESERVE_CUS wins)
-    if (world > 1 && c->reserve_cus < 0) c->reserve_cus = kDefaultReservedCus;
+    if (world > 1 && c->reserve_cus < 0) {
+        c->reserve_cus = kDefaultReservedCus;
+        d->defaulted_reserve = true;
+    }
     *out = d;
+    return FLO_OK;
+}
+
+extern "C" int flo_dist_table_submit(flo_dist *d, flo_batch *b, size_t max_clips) {
+    if (!d || !b) return FLO_ERR_ARG;
+    flo_ctx *c = d->ctx;
+    if (b->ctx != c) return fail(c, FLO_ERR_ARG, "batch and communicator belong to different contexts");
+    if (!b->synced) return fail(c, FLO_ERR_STATE, "call flo_batch_encode + flo_batch_sync first");
+    if (b->n_clips > max_clips) return fail(c, FLO_ERR_ARG, "flo_dist_table_submit: max_clips is smaller than this rank's clip count");
+    HIPCHK(c, hipSetDevice(c->device));
+    RcclBackend &be = d->be;
+    TableSlot &t = d->tab[d->tab_steps & 1];
+    const size_t words = 1 + 3 * max_clips;
+    if (t.used) HIPCHK(c, hipEventSynchronize(t.done));   // this slot's previous round trip (two steps ago): long over
+    if (t.words < words) {
+        if (t.h_mine) hipHostFree(t.h_mine);
+        if (t.h_all) hipHostFree(t.h_all);
+        if (t.d_mine) hipFree(t.d_mine);
+        if (t.d_all) hipFree(t.d_all);
+        t.h_mine = t.h_all = t.d_mine = t.d_all = nullptr;
+        t.words = 0;
+        if (hipHostMalloc(&t.h_mine, words * 8) != hipSuccess || hipHostMalloc(&t.h_all, words * 8 * (size_t)be.world) != hipSuccess ||
+            hipMalloc(&t.d_mine, words * 8) != hipSuccess || hipMalloc(&t.d_all, words * 8 * (size_t)be.world) != hipSuccess)
+            return fail(c, FLO_ERR_NOMEM, "flo_dist_table_submit: buffers");
+        if (!t.done && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) return fail(c, FLO_ERR_NOMEM, "flo_dist_table_submit: event");
+        t.words = words;
+    }
+    const uint8_t *base;
+    const uint64_t *offs, *sizes;
+    int rc = flo_batch_device_files(b, &base, &offs, &sizes);
+    if (rc != FLO_OK) return rc;
+    memset(t.h_mine, 0, words * 8);
+    t.h_mine[0] = b->n_clips;
+    for (size_t i = 0; i < b->n_clips; i++) {
+        t.h_mine[1 + i] = sizes[i];
+        t.h_mine[1 + max_clips + i] = offs[i];
+    }
+    HIPCHK(c, hipMemcpyAsync(t.d_mine, t.h_mine, words * 8, hipMemcpyHostToDevice, be.cs));
+    // (the batch is synced: its files, CRC fields included, are complete; nothing on the encode stream to wait for)
+    if (flo::launch_table_crcs(base, (unsigned long long *)t.d_mine, b->n_clips, max_clips, be.cs) != 0)
+        return fail(c, FLO_ERR_DEVICE, "flo_dist_table_submit: table kernel");
+    NCCLRC(c, ncclAllGather(t.d_mine, t.d_all, words, ncclUint64, be.comm, be.cs));
+    HIPCHK(c, hipMemcpyAsync(t.h_all, t.d_all, words * 8 * (size_t)be.world, hipMemcpyDeviceToHost, be.cs));
+    HIPCHK(c, hipEventRecord(t.done, be.cs));
+    t.used = true;
+    d->tab_max = max_clips;
+    d->tab_steps++;
+    return FLO_OK;
+}
+
+extern "C" int flo_dist_table_flush(flo_dist *d) {
+    if (!d) return FLO_ERR_ARG;
+    HIPCHK(d->ctx, hipSetDevice(d->ctx->device));
+    for (auto &t : d->tab)
+        if (t.used) HIPCHK(d->ctx, hipEventSynchronize(t.done));
+    return FLO_OK;
+}
+
+extern "C" int flo_dist_table_result(flo_dist *d, const uint64_t **rows, size_t *row_words, size_t *max_clips) {
+    if (!d) return FLO_ERR_ARG;
+    if (!d->tab_steps) return fail(d->ctx, FLO_ERR_STATE, "no table has been submitted yet");
+    const TableSlot &t = d->tab[(d->tab_steps - 1) & 1];
+    HIPCHK(d->ctx, hipEventSynchronize(t.done));
+    if (rows) *rows = t.h_all;
+    if (row_words) *row_words = 1 + 3 * d->tab_max;
+    if (max_clips) *max_clips = d->tab_max;
     return FLO_OK;
 }
 
@@ -1929,6 +2018,7 @@ extern "C" int flo_ctx_reserve_cus(flo_ctx *c, int n) {
     c->reserve_cus = n;
     return FLO_OK;
 }
+extern "C" int flo_ctx_reserved_cus(flo_ctx *c) { return c ? (c->reserve_cus > 0 ? c->reserve_cus : 0) : -1; }
 
 // ------------------------------------------------------------------------------------------------ streaming encoder
 // StreamingEncoder of libflo/src/streaming/encoder.rs on the device library: samples are pushed, complete one-second

@@ -77,6 +77,26 @@ class NativeGather:
         self.ctx._chk(self._L.flo_dist_gather_result(self._h, C.byref(base), C.byref(offs), C.byref(sizes)))
         return base.value, [offs[i] for i in range(self.world)], [sizes[i] for i in range(self.world)]
 
+    # second exchange mode: the files stay on their ranks, every rank learns (offset, size, CRC32) of every file
+    def table_submit(self, batch, max_clips: int):
+        self.ctx._chk(self._L.flo_dist_table_submit(self._h, batch._h, max_clips))
+
+    def table_flush(self):
+        self.ctx._chk(self._L.flo_dist_table_flush(self._h))
+
+    def table_result(self):
+        """per rank: (sizes, offsets, crc32s) of its clips, as the last submitted step left them"""
+        rows, words, mx = C.POINTER(C.c_uint64)(), C.c_size_t(), C.c_size_t()
+        self.ctx._chk(self._L.flo_dist_table_result(self._h, C.byref(rows), C.byref(words), C.byref(mx)))
+        out = []
+        for r in range(self.world):
+            base = r * words.value
+            n = int(rows[base])
+            out.append(([int(rows[base + 1 + i]) for i in range(n)],
+                        [int(rows[base + 1 + mx.value + i]) for i in range(n)],
+                        [int(rows[base + 1 + 2 * mx.value + i]) for i in range(n)]))
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.flo_dist_destroy(self._h)

@@ -169,11 +169,26 @@ int flo_dist_gather_flush(flo_dist *d);
  * in their headers) lie at base + rank_offsets[r], rank_sizes[r] bytes, in device memory owned by d */
 int flo_dist_gather_result(flo_dist *d, const uint8_t **base, const uint64_t **rank_offsets, const uint64_t **rank_sizes);
 void *flo_dist_stream(flo_dist *d);   /* hipStream_t of the communication stream */
+/* Second exchange mode, offered beside the gather (the gather is what the path's single exchange step is; this shows what
+ * the encode scales to when the root's link ingress is not in the way): the files stay on the ranks that made them and
+ * ONE ncclAllGather of 24 bytes per clip tells every rank where each file of every rank lies (byte offset in its
+ * owner's device buffer), how long it is and the CRC32 of its DATA chunk. max_clips = the largest clip count of any
+ * rank (the same value on all ranks). Asynchronous on the communication stream, double-buffered like the gather.
+ *   per step: flo_batch_encode(b, 0); flo_batch_sync(b); flo_dist_table_submit(d, b, max_clips);
+ *   at the end: flo_dist_table_flush(d);  every rank: flo_dist_table_result(d, &rows, &row_words, &max_clips)
+ * rows = host memory owned by d, `world` rows of row_words u64: [0] the rank's clip count | [1 .. max] sizes |
+ * [1 + max .. 2 max] offsets | [1 + 2 max .. 3 max] CRC32 values (of the last submitted step). */
+int flo_dist_table_submit(flo_dist *d, flo_batch *b, size_t max_clips);
+int flo_dist_table_flush(flo_dist *d);
+int flo_dist_table_result(flo_dist *d, const uint64_t **rows, size_t *row_words, size_t *max_clips);
 /* The persistent encode kernels start one workgroup per compute unit; RCCL's send / receive are kernels too, so with
  * more than one rank the library leaves `n` compute units free for them (default 8 once a communicator with world > 1
  * exists, 0 otherwise; the environment variable FLO_RESERVE_CUS sets it at context creation). Costs n / 256 of the
  * single-GPU rate; without it the transfer of step k cannot start before the encode of step k + 1 has ended. */
 int flo_ctx_reserve_cus(flo_ctx *ctx, int n);
+/* compute units the persistent encode kernels currently leave free (0 when nothing is reserved). A reservation that
+ * flo_dist_create made by default ends with flo_dist_destroy; one set by the caller or FLO_RESERVE_CUS stays. */
+int flo_ctx_reserved_cus(flo_ctx *ctx);
 
 /* ---- analysis metadata: what libflo::encode / encode_lossy / encode_with_bitrate add to META (lib.rs:219-283) -------
  * flo_analyze computes, on the device, what add_analysis_data_if_missing computes from the samples: waveform peaks

@@ -63,6 +63,39 @@ def test_single_rank_gather_returns_the_batch_files(ctx):
     g.close()
 
 
+def test_single_rank_table_names_every_file(ctx):
+    # the second exchange mode: files stay where they are, one all-gather of (size, offset, CRC32) per clip. With one rank
+    # the whole code path runs (table kernel, ncclAllGather, both slots); the rows must describe the batch's files.
+    import zlib
+    import flo_amd
+    from flo_amd.dist import NativeGather, unique_id
+    lens = [0, 1000, 44100, 70001, 3 * 1024]
+    clips = [signals.music_like(44100, n, 2, seed=80 + i) for i, n in enumerate(lens)]
+    assert ctx.reserved_cus() == 0
+    g = NativeGather(ctx, unique_id(), 0, 1, 0)
+    assert ctx.reserved_cus() == 0          # a one-rank communicator reserves nothing
+    for mode, qol in ((flo_amd.MODE_LOSSY, 0.55), (flo_amd.MODE_LOSSLESS, 5)):
+        b = flo_amd.Batch(ctx, mode, [c.size for c in clips], 44100, 2, qol)
+        for i, c in enumerate(clips):
+            b.upload(i, c)
+        for step in range(3):
+            b.encode(0)
+            b.sync()
+            g.table_submit(b, max_clips=len(clips) + 3)
+        g.table_flush()
+        (sizes, offs, crcs), = g.table_result()
+        assert len(sizes) == len(clips)
+        for i in range(len(clips)):
+            f = b.fetch(i)
+            assert sizes[i] == len(f), (mode, i)
+            assert crcs[i] == zlib.crc32(flofile.parse(f).data), (mode, i)
+        assert sorted(offs) == offs and len(set(offs)) == len(offs)
+        with pytest.raises(flo_amd.FloError, match="max_clips"):
+            g.table_submit(b, max_clips=2)
+        b.close()
+    g.close()
+
+
 def _rank_main(rank, world, idq, outq):
     try:
         import flo_amd
@@ -75,6 +108,9 @@ def _rank_main(rank, world, idq, outq):
         else:
             tok = idq.get(timeout=120)
         g = NativeGather(c, tok, rank, world, 0)
+        # with more than one rank the persistent encode kernels leave compute units to RCCL's kernels by default: the
+        # first ncclSend / ncclRecv under the reserved-CU launch is then a tested configuration
+        assert c.reserved_cus() == 8, c.reserved_cus()
         lens = [5000 + 777 * rank, 30000, 1024 * (rank + 1)]
         clips = [signals.music_like(44100, n, 2, seed=100 * rank + i) for i, n in enumerate(lens)]
         b = flo_amd.Batch(c, flo_amd.MODE_LOSSY, [x.size for x in clips], 44100, 2, 0.55)
@@ -86,13 +122,18 @@ def _rank_main(rank, world, idq, outq):
             g.submit(b)
         g.flush()
         mine = [b.fetch(i) for i in range(len(clips))]
+        g.table_submit(b, max_clips=4)
+        g.table_flush()
+        table = g.table_result()
+        assert [len(t[0]) for t in table] == [3] * world and table[rank][0] == [len(f) for f in mine]
         if rank == 0:
             base, offs, sizes = g.result()
             got = [_split_files(_d2h(base + offs[r], sizes[r])) for r in range(world)]
-            outq.put(("root", got, mine))
+            outq.put(("root", got, mine, table))
         else:
             outq.put(("peer", rank, mine))
         g.close()
+        assert c.reserved_cus() == 0     # the default reservation ends with the communicator
         c.close()
     except Exception as e:   # noqa: BLE001
         outq.put(("error", rank, repr(e)))
@@ -128,3 +169,26 @@ def test_two_ranks_on_one_gpu_if_rccl_allows_it():
     got = root[1]
     assert got[0] == root[2]          # the root's own files
     assert got[1] == peer[2]          # the peer's files arrived byte for byte
+    assert root[3][1][0] == [len(f) for f in peer[2]]    # and the table mode names the peer's files by size
+
+
+def test_bench_exchange_legs_with_one_rank():
+    # bench.py's multi-GPU legs (the gather inside `value`, the strong-scaling shard of configs[3], the table mode) run
+    # here with a one-rank communicator: the keys the driver's N > 1 runs will carry exist and hold sane numbers
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchange", "--clips-per-gpu", "96", "--clip-seconds", "1",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-single-clip", "--no-lossless", "--no-shard", "--no-e2e"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]
+    d = json.loads(line)
+    ex = d["exchange_detail"]
+    assert d["value"] > 0 and ex["valid"] is True and "byte for byte" in ex["self_check"] and ex["reserved_cus"] == 0
+    s, t = ex["strong_96"], ex["table_exchange"]
+    assert s["scaling"] == "strong" and s["value"] > 0 and s["encode_only"]["value"] >= s["value"] * 0.5
+    assert len(s["bytes_per_rank_per_step"]) == 1 and s["bytes_per_rank_per_step"][0] > 96 * 1000
+    assert t["files_named"] == 96 and t["bytes_named"] > 96 * 1000 and t["value"] > 0
+    assert ex["encode_only"]["value"] > 0 and ex["bytes_per_rank_per_step"][0] > 0
