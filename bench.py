@@ -504,7 +504,10 @@ def main():
             ctx.encode_batch(flo_amd.MODE_LOSSY, clips, sr, ch, args.quality)
             d7 = time.perf_counter() - t7
             best = d7 if best is None else min(best, d7)
+        up_name, up_direct, up_ring = ctx.upload_path()
         out["e2e"] = {"note": "host buffers in, .flo files out (H2D + encode + D2H through the C ABI); not the headline",
+                      "upload_path": {"large_uploads": up_name, "probe_pageable_direct_GBs": round(up_direct, 1), "probe_pinned_ring_GBs": round(up_ring, 1),
+                                      "note": "chosen once per context by timing both on 24 MB; one clip always goes direct"},
                       "flo_encode_lossy_10s_clip_ms": round(d6 * 1e3, 4),
                       "flo_encode_lossy_10s_clip_Msamples_s": round(n_il / d6 / 1e6, 1),
                       "flo_encode_batch_64x10s_ms": round(best * 1e3, 3),

@@ -25,7 +25,7 @@ EXPORTS = [
     "flo_ctx_profile_enable", "flo_ctx_profile_query", "flo_ctx_profile_reset", "flo_ctx_force_path", "flo_ctx_stream",
     "flo_mdct_forward", "flo_lossy_analyze", "flo_lossy_quantize", "flo_sparse_pack",
     "flo_dist_unique_id", "flo_dist_create", "flo_dist_destroy", "flo_dist_gather_submit", "flo_dist_gather_flush",
-    "flo_dist_gather_result", "flo_dist_stream", "flo_ctx_reserve_cus", "flo_ctx_reserved_cus",
+    "flo_dist_gather_result", "flo_dist_stream", "flo_ctx_reserve_cus", "flo_ctx_reserved_cus", "flo_ctx_upload_path",
     "flo_dist_table_submit", "flo_dist_table_flush", "flo_dist_table_result",
     "flo_stream_create", "flo_stream_destroy", "flo_stream_push", "flo_stream_pending_samples", "flo_stream_pending_frames",
     "flo_stream_next_frame", "flo_stream_flush", "flo_stream_finalize",
@@ -122,6 +122,7 @@ def lib():
     L.flo_dist_stream.restype = vp
     L.flo_ctx_reserve_cus.argtypes = [vp, C.c_int]
     L.flo_ctx_reserve_cus.restype = C.c_int
+    L.flo_ctx_upload_path.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.flo_ctx_reserved_cus.argtypes = [vp]
     L.flo_ctx_reserved_cus.restype = C.c_int
     L.flo_dist_table_submit.argtypes = [vp, vp, C.c_size_t]

@@ -119,6 +119,12 @@ class Context:
         """compute units the persistent encode kernels currently leave free"""
         return int(self._L.flo_ctx_reserved_cus(self._h))
 
+    def upload_path(self):
+        """(path large host uploads take on this host, GB/s the probe measured for pageable-direct, for the pinned ring)"""
+        name, a, b = C.create_string_buffer(64), C.c_double(), C.c_double()
+        self._chk(self._L.flo_ctx_upload_path(self._h, name, 64, C.byref(a), C.byref(b)))
+        return name.value.decode(), a.value, b.value
+
     # -- one clip ---------------------------------------------------------------------------------------
 
     def encode_lossy(self, samples, sample_rate, channels, quality, metadata=b"") -> bytes:

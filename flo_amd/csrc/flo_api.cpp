@@ -1005,15 +1005,17 @@ extern "C" int flo_encode_batch(flo_ctx *c, int mode, size_t n_clips, const floa
         const double tb = tnow();
         if (hipEventCreateWithFlags(&k.up, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&k.enc, hipEventDisableTiming) != hipSuccess)
             return cleanup(fail(c, FLO_ERR_DEVICE, "hipEventCreate"));
+        // (errors leave through cleanup(): the chunks' batches, pinned blocks and events are released, outs[] stays empty)
+        auto ordered = [&](hipError_t e, const char *what) { return e == hipSuccess ? FLO_OK : fail(c, FLO_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e)); };
         // the batch's padding memset ran on the ctx stream: the uploads must land behind it
-        HIPCHK(c, hipEventRecord(k.enc, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->up_stream, k.enc, 0));
+        if ((rc = ordered(hipEventRecord(k.enc, c->stream), "hipEventRecord")) != FLO_OK) return cleanup(rc);
+        if ((rc = ordered(hipStreamWaitEvent(c->up_stream, k.enc, 0), "hipStreamWaitEvent")) != FLO_OK) return cleanup(rc);
         if ((rc = batch_upload_all(k.b, pcm + k.first, c->up_stream)) != FLO_OK) return cleanup(rc);
         const double tc = tnow();
-        HIPCHK(c, hipEventRecord(k.up, c->up_stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, k.up, 0));
+        if ((rc = ordered(hipEventRecord(k.up, c->up_stream), "hipEventRecord")) != FLO_OK) return cleanup(rc);
+        if ((rc = ordered(hipStreamWaitEvent(c->stream, k.up, 0), "hipStreamWaitEvent")) != FLO_OK) return cleanup(rc);
         if ((rc = flo_batch_encode(k.b, 0)) != FLO_OK) return cleanup(rc);
-        HIPCHK(c, hipEventRecord(k.enc, c->stream));   // this chunk's files are finished behind this point
+        if ((rc = ordered(hipEventRecord(k.enc, c->stream), "hipEventRecord")) != FLO_OK) return cleanup(rc);   // this chunk's files are finished behind this point
         k.encoded = true;
         const double td = tnow();
         if (ci > 0 && (rc = take(chunks[ci - 1])) != FLO_OK) return cleanup(rc);
@@ -2016,6 +2018,14 @@ extern "C" void *flo_dist_stream(flo_dist *d) { return d ? (void *)d->be.cs : nu
 extern "C" int flo_ctx_reserve_cus(flo_ctx *c, int n) {
     if (!c || n < 0 || n >= c->prop.multiProcessorCount) return FLO_ERR_ARG;
     c->reserve_cus = n;
+    return FLO_OK;
+}
+extern "C" int flo_ctx_upload_path(flo_ctx *c, char *name, size_t cap, double *direct_gbs, double *ring_gbs) {
+    if (!c) return FLO_ERR_ARG;
+    int rc = ctx_stager(c);
+    if (rc != FLO_OK) return rc;
+    const char *n = stager_upload_choice(c->stager, direct_gbs, ring_gbs);
+    if (name && cap) snprintf(name, cap, "%s", n);
     return FLO_OK;
 }
 extern "C" int flo_ctx_reserved_cus(flo_ctx *c) { return c ? (c->reserve_cus > 0 ? c->reserve_cus : 0) : -1; }

@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -15,10 +16,12 @@ namespace {
 constexpr size_t kSlotBytes = (size_t)8 << 20;   // ring slot
 constexpr int kSlots = 4;
 constexpr size_t kPiece = (size_t)512 << 10;     // unit of work handed to a worker thread
-// Uploads up to this size go through the runtime's own pageable path (hipMemcpyAsync straight from the caller's memory): on
-// the hosts of this pool it moves 43 GB/s, the ring with six copying threads 30 - 35 (64 x 3.5 MB: 6.8 ms against 8.3),
-// so the ring is what an override (FLO_SMALL_UPLOAD_MB) or a single transfer beyond 1 GiB gets.
-constexpr size_t kSmallUpload = (size_t)1 << 30;
+// Uploads up to this size always go through the runtime's own pageable path (hipMemcpyAsync straight from the caller's
+// memory): waking the copy threads costs more than they save. Beyond it the faster of the two paths is used, and which
+// one that is depends on the HOST (round 3 measured 43 GB/s pageable against 30 - 35 through the ring on one host and a
+// factor of two the other way on another), so it is measured once per context on the first large upload (probe()).
+constexpr size_t kSmallUpload = (size_t)8 << 20;
+constexpr size_t kProbeBytes = (size_t)24 << 20;   // three ring slots: the ring's steady state, not its first slot
 }  // namespace
 
 class Stager {
@@ -49,6 +52,8 @@ class Stager {
     std::vector<PinBlock> blocks;   // pinned download buffers, kept for the next call
     hipStream_t aux_stream = nullptr;   // the second uploading thread's stream and its "done" event
     hipEvent_t aux_ev = nullptr, aux_go = nullptr;
+    int large_path = 0;                 // 0 not measured yet, 1 pageable-direct, 2 pinned ring
+    double probe_direct_gbs = 0, probe_ring_gbs = 0;
 
     void worker() {
         std::unique_lock<std::mutex> lk(mu);
@@ -176,15 +181,65 @@ void stager_memcpy_many(Stager *s, const std::vector<UploadSeg> &segs) {
     s->run(std::move(js));
 }
 
+static int upload_direct(Stager *s, const std::vector<UploadSeg> &segs, size_t total, hipStream_t stream, std::string &err);
+static int upload_ring(Stager *s, const std::vector<UploadSeg> &segs, hipStream_t stream, std::string &err);
+
+// Which path moves a large upload faster on THIS host: both are timed once on kProbeBytes of scratch (pageable memory that
+// has been touched, as a caller's buffer has) into device scratch, on a stream of the probe's own, until the data is
+// on the device. About ten milliseconds, once per context. FLO_UPLOAD_PATH=direct|ring skips it.
+static void probe(Stager *s) {
+    if (const char *e = getenv("FLO_UPLOAD_PATH")) {
+        if (!strcmp(e, "direct")) { s->large_path = 1; return; }
+        if (!strcmp(e, "ring")) { s->large_path = 2; return; }
+    }
+    s->large_path = 2;   // what an incomplete probe leaves: the ring does not block the calling thread per copy
+    char *host = (char *)malloc(kProbeBytes);
+    void *dev = nullptr;
+    hipStream_t st = nullptr;
+    if (host && hipMalloc(&dev, kProbeBytes) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
+        memset(host, 1, kProbeBytes);
+        std::string err;
+        std::vector<UploadSeg> segs;
+        for (size_t o = 0; o < kProbeBytes; o += (size_t)4 << 20) segs.push_back({(char *)dev + o, host + o, (size_t)4 << 20});
+        double t[2] = {0, 0};
+        bool ok = ensure_ring(s, err);
+        for (int pass = 0; ok && pass < 2; pass++)        // the first pass warms both paths up (page tables, threads)
+            for (int which = 0; ok && which < 2; which++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                ok = (which ? upload_ring(s, segs, st, err) : upload_direct(s, segs, kProbeBytes, st, err)) == 0 && hipStreamSynchronize(st) == hipSuccess;
+                t[which] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
+        if (ok && t[0] > 0 && t[1] > 0) {
+            s->probe_direct_gbs = kProbeBytes / t[0] / 1e9;
+            s->probe_ring_gbs = kProbeBytes / t[1] / 1e9;
+            s->large_path = t[0] < t[1] ? 1 : 2;
+        }
+    }
+    if (st) hipStreamDestroy(st);
+    if (dev) hipFree(dev);
+    free(host);
+}
+
+const char *stager_upload_choice(Stager *s, double *direct_gbs, double *ring_gbs) {
+    if (direct_gbs) *direct_gbs = s->probe_direct_gbs;
+    if (ring_gbs) *ring_gbs = s->probe_ring_gbs;
+    return s->large_path == 1 ? "pageable-direct" : (s->large_path == 2 ? "pinned-ring" : "not measured yet");
+}
+
 int stager_upload(Stager *s, const std::vector<UploadSeg> &segs, hipStream_t stream, std::string &err) {
-    // a few megabytes: waking the copy threads costs more than they save; the runtime's own pageable path is used
     size_t total = 0;
     for (const UploadSeg &g : segs) total += g.bytes;
     static const size_t small_limit = [] {   // diagnostic override (MiB)
         const char *e = getenv("FLO_SMALL_UPLOAD_MB");
         return e ? (size_t)atoi(e) << 20 : kSmallUpload;
     }();
-    if (total <= small_limit) {
+    if (total <= small_limit) return upload_direct(s, segs, total, stream, err);
+    if (!s->large_path) probe(s);
+    return s->large_path == 1 ? upload_direct(s, segs, total, stream, err) : upload_ring(s, segs, stream, err);
+}
+
+static int upload_direct(Stager *s, const std::vector<UploadSeg> &segs, size_t total, hipStream_t stream, std::string &err) {
+    {
         // FLO_UPLOAD_THREADS=2: a second thread issues half of the copies on a stream of its own. Measured: 6.2 - 6.9 ms
         // against 6.8 - 6.9 for 64 x 3.5 MB alone in a process, but 12.0 against 6.5 inside bench.py's process on another
         // host: the runtime serialises most of it and the extra thread is at the scheduler's mercy. Off by default.
@@ -235,6 +290,9 @@ int stager_upload(Stager *s, const std::vector<UploadSeg> &segs, hipStream_t str
         }
         return 0;
     }
+}
+
+static int upload_ring(Stager *s, const std::vector<UploadSeg> &segs, hipStream_t stream, std::string &err) {
     if (!ensure_ring(s, err)) return -1;
     // walk the segments, cutting them at ring-slot boundaries: a slot is filled by the worker threads, then handed to
     // the copy engine (one asynchronous copy per piece of a segment), while the next slot is being filled

@@ -186,6 +186,11 @@ int flo_dist_table_result(flo_dist *d, const uint64_t **rows, size_t *row_words,
  * exists, 0 otherwise; the environment variable FLO_RESERVE_CUS sets it at context creation). Costs n / 256 of the
  * single-GPU rate; without it the transfer of step k cannot start before the encode of step k + 1 has ended. */
 int flo_ctx_reserve_cus(flo_ctx *ctx, int n);
+/* Host-buffer entry points (flo_encode_*): which path uploads beyond 8 MB take on this host - "pageable-direct" (the
+ * runtime's copy straight from the caller's memory) or "pinned-ring" (copy threads + pinned staging) - and the rates the
+ * one-time probe measured for both (GB/s; 0 and "not measured yet" before the first large upload). A single clip always
+ * goes direct. FLO_UPLOAD_PATH=direct|ring overrides the probe. */
+int flo_ctx_upload_path(flo_ctx *ctx, char *name, size_t name_cap, double *direct_gbs, double *ring_gbs);
 /* compute units the persistent encode kernels currently leave free (0 when nothing is reserved). A reservation that
  * flo_dist_create made by default ends with flo_dist_destroy; one set by the caller or FLO_RESERVE_CUS stays. */
 int flo_ctx_reserved_cus(flo_ctx *ctx);
