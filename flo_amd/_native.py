@@ -23,7 +23,7 @@ EXPORTS = [
     "flo_batch_device_streams", "flo_batch_pack_streams", "flo_batch_decode",
     "flo_batch_device_files", "flo_batch_pack_files",
     "flo_ctx_profile_enable", "flo_ctx_profile_query", "flo_ctx_profile_reset", "flo_ctx_force_path", "flo_ctx_stream",
-    "flo_mdct_forward", "flo_lossy_analyze", "flo_lossy_quantize", "flo_sparse_pack",
+    "flo_mdct_forward", "flo_lossy_analyze", "flo_lossy_quantize", "flo_lossy_quantize_smr", "flo_sparse_pack",
     "flo_dist_unique_id", "flo_dist_create", "flo_dist_destroy", "flo_dist_gather_submit", "flo_dist_gather_flush",
     "flo_dist_gather_result", "flo_dist_stream", "flo_ctx_reserve_cus", "flo_ctx_reserved_cus", "flo_ctx_upload_path",
     "flo_dist_table_submit", "flo_dist_table_flush", "flo_dist_table_result",
@@ -110,6 +110,7 @@ def lib():
     L.flo_mdct_forward.argtypes = [vp, vp, sz, vp]
     L.flo_lossy_analyze.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_float, vp, vp, vp, C.POINTER(sz)]
     L.flo_lossy_quantize.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint8, C.c_float, C.c_int, vp, vp]
+    L.flo_lossy_quantize_smr.argtypes = [vp, vp, vp, sz, C.c_uint32, C.c_float, vp, vp]
     L.flo_sparse_pack.argtypes = [vp, vp, sz, C.c_int, vp, sz, vp]
     L.flo_dist_unique_id.argtypes = [vp]
     L.flo_dist_create.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]

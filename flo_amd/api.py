@@ -225,6 +225,21 @@ class Context:
                                              q.ctypes.data, sfw.ctypes.data))
         return dict(q=q, sf_words=sfw)
 
+    def lossy_quantize_smr(self, coeffs, smr, sample_rate, quality):
+        """TransformEncoder::quantize_coefficients on the device (encoder.rs:109-154): vectors of 1024 coefficients and the
+        caller's signal-to-mask ratios -> (i16 [n][1024], f32 scale factors [n][25]); smr=None: scale factors only."""
+        c = np.ascontiguousarray(coeffs, np.float32).reshape(-1, 1024)
+        n = c.shape[0]
+        sf = np.zeros((n, 25), np.float32)
+        if smr is None:
+            self._chk(self._L.flo_lossy_quantize_smr(self._h, c.ctypes.data, None, n, sample_rate, quality, None, sf.ctypes.data))
+            return None, sf
+        m = np.ascontiguousarray(smr, np.float32).reshape(-1, 1024)
+        assert m.shape == c.shape
+        q = np.zeros((n, 1024), np.int16)
+        self._chk(self._L.flo_lossy_quantize_smr(self._h, c.ctypes.data, m.ctypes.data, n, sample_rate, quality, q.ctypes.data, sf.ctypes.data))
+        return q, sf
+
     def sparse_pack(self, q, form=0):
         """serialize_sparse on the device. form 0: as the encoder packs (item form, behind it the block form, behind that the
         general form for dense vectors); form 1: the general form for every vector; form 2: block form, then general."""
@@ -379,16 +394,62 @@ class Decoder:
         return self._ctx.decode(data)
 
 
+class TransformFrame:
+    """lossy::TransformFrame (lossy/mod.rs): what encode_frame returns - per channel the 1024 quantised coefficients and the
+    25 band scale factors; `scale_words` are the u16 words the container stores for them (encoder.rs:262-266)."""
+
+    def __init__(self, coefficients, scale_factors, scale_words):
+        self.coefficients, self.scale_factors, self.scale_words = coefficients, scale_factors, scale_words
+        self.block_size, self.num_samples = 2048, 1024
+
+
 class TransformEncoder:
-    """lossy::TransformEncoder — lossy/encoder.rs:6-53,167-239. One fresh encoder per clip is the contract."""
+    """lossy::TransformEncoder — lossy/encoder.rs:6-53,63-164,167-239. One fresh encoder per clip is the contract."""
+
+    _HISTORY = 65   # frames whose masking levels can still reach the newest one: the temporal step is max(a_t, 0.7 s_{t-1}),
+                    # and the frame-parallel kernels resolve it exactly from a 64-frame warm-up (tests compare them to the chain)
 
     def __init__(self, sample_rate: int, channels: int, quality: float, ctx: Context = None):
         self.sample_rate, self.channels = sample_rate, channels
         self.quality = float(min(max(quality, 0.0), 1.0))
         self._ctx = ctx
+        self._spectra = []   # the last _HISTORY frames' coefficients [ch][1024]: the psychoacoustic model's temporal state
 
     def set_quality(self, quality: float):
         self.quality = float(min(max(quality, 0.0), 1.0))
+
+    def reset(self):
+        """encoder.rs:157-164: forget the temporal masking state (and the transform's, which keeps none here)"""
+        self._spectra = []
+
+    def encode_frame(self, samples) -> TransformFrame:
+        """encoder.rs:63-106: one block of 2048 sample-frames (interleaved; shorter blocks are zero-padded) -> its quantised
+        spectrum. Stateful like the reference: the masking thresholds of a frame depend on the frames encoded before it
+        (psychoacoustic.rs:196-203), so the device pass runs over the kept spectra and the newest frame's result is returned."""
+        ctx = self._ctx or default_context()
+        x = _f32(samples)
+        ch = self.channels
+        per = x.size // ch + (1 if x.size % ch else 0)
+        block = np.zeros((ch, 2048), np.float32)
+        for c in range(ch):
+            d = x[c::ch][:2048]
+            block[c, :d.size] = d
+        assert per <= 2048, "encode_frame takes one block (2048 sample-frames)"
+        spec = ctx.mdct_forward(block.reshape(-1))            # [ch][1024], device
+        self._spectra.append(spec)
+        if len(self._spectra) > self._HISTORY:
+            self._spectra.pop(0)
+        g = ctx.lossy_quantize(np.stack(self._spectra), self.sample_rate, self.quality)
+        _, sf = ctx.lossy_quantize_smr(spec, None, self.sample_rate, self.quality)
+        return TransformFrame([g["q"][-1, c].copy() for c in range(ch)], [sf[c].copy() for c in range(ch)],
+                              [g["sf_words"][-1, c].copy() for c in range(ch)])
+
+    def quantize_coefficients(self, coeffs, smr):
+        """encoder.rs:109-154: (quantised i16 [1024], scale factors f32 [25]) of one channel's coefficients under the
+        caller's signal-to-mask ratios, on the device"""
+        ctx = self._ctx or default_context()
+        q, sf = ctx.lossy_quantize_smr(coeffs, smr, self.sample_rate, self.quality)
+        return q[0], sf[0]
 
     def encode_to_flo(self, samples, metadata: bytes = b"") -> bytes:
         ctx = self._ctx or default_context()

@@ -1207,6 +1207,36 @@ extern "C" int flo_lossy_quantize(flo_ctx *c, const float *coeffs, size_t num_ho
     return analyze_common(c, nullptr, 0, coeffs, num_hops, sr, ch, quality, exact, nullptr, q, sfw, nullptr);
 }
 
+extern "C" int flo_lossy_quantize_smr(flo_ctx *c, const float *coeffs, const float *smr, size_t n_vec, uint32_t sr, float quality,
+                                      int16_t *q, float *scale_factors) {
+    if (!c || (n_vec && (!coeffs || !scale_factors || (smr && !q)))) return FLO_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!n_vec) return FLO_OK;
+    TableSet *ts;
+    int rc = get_tables(c, sr, quality, &ts);
+    if (rc != FLO_OK) return rc;
+    float *d_c = nullptr, *d_smr = nullptr, *d_sf = nullptr;
+    short *d_q = nullptr;
+    hipError_t e = hipMalloc(&d_c, n_vec * 4096);
+    if (e == hipSuccess) e = hipMalloc(&d_sf, n_vec * 100);
+    if (e == hipSuccess && smr) e = hipMalloc(&d_smr, n_vec * 4096);
+    if (e == hipSuccess && smr) e = hipMalloc(&d_q, n_vec * 2048);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_c, coeffs, n_vec * 4096, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && smr) e = hipMemcpyAsync(d_smr, smr, n_vec * 4096, hipMemcpyHostToDevice, c->stream);
+    int lrc = 0;
+    if (e == hipSuccess) lrc = launch_quantise_smr(ts->dev, d_c, d_smr, n_vec, d_q, d_sf, c->stream);
+    if (e == hipSuccess && lrc == 0) e = hipMemcpyAsync(scale_factors, d_sf, n_vec * 100, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && lrc == 0 && smr) e = hipMemcpyAsync(q, d_q, n_vec * 2048, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    hipFree(d_c);
+    if (d_smr) hipFree(d_smr);
+    if (d_sf) hipFree(d_sf);
+    if (d_q) hipFree(d_q);
+    if (e != hipSuccess || e2 != hipSuccess || lrc != 0)
+        return fail(c, FLO_ERR_DEVICE, std::string("flo_lossy_quantize_smr: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return FLO_OK;
+}
+
 extern "C" int flo_sparse_pack(flo_ctx *c, const int16_t *q, size_t n_vec, int form, uint8_t *out, size_t out_cap,
                                uint32_t *out_off) {
     if (!c || (n_vec && (!q || !out || !out_off)) || form < 0 || form > 2) return FLO_ERR_ARG;

@@ -1322,6 +1322,45 @@ __global__ __launch_bounds__(64) void mdct_only_kernel(LossyDevTables T, const f
     for (int q = 0; q < 4; q++) d[q] = make_float4(c[0][4 * q], c[0][4 * q + 1], c[0][4 * q + 2], c[0][4 * q + 3]);
 }
 
+// TransformEncoder::quantize_coefficients (encoder.rs:109-154) as the reference exposes it: the caller brings the per-coefficient
+// signal-to-mask ratios, the kernel makes the band scale factors (30000 / band maximum, IEEE division) and quantises every
+// coefficient whose ratio exceeds the quality's threshold. One wave per vector of 1024 coefficients; band maxima through
+// LDS atomics on the bit patterns (non-negative floats order like their bits). smr == nullptr: scale factors only.
+__global__ __launch_bounds__(64) void quantise_smr_kernel(LossyDevTables T, const float *coeffs, const float *smr, unsigned long long n,
+                                                          short *q, float *sf_out) {
+    __shared__ uint32_t bmax[32];
+    const unsigned long long w = blockIdx.x;
+    if (w >= n) return;
+    const int lane = lane_id();
+    if (lane < 32) bmax[lane] = 0u;
+    __syncthreads();
+    const float *c = coeffs + w * 1024;
+    for (int k = lane; k < 1024; k += 64) {
+        const float a = fabsf(c[k]);
+        if (a == a) atomicMax(&bmax[T.band[k]], __float_as_uint(a));   // f32::max ignores a NaN operand
+    }
+    __syncthreads();
+    float sf = 1.0f;
+    if (lane < 25) {
+        const float m = __uint_as_float(bmax[lane]);
+        if (m > 1e-10f) sf = __fdiv_rn(30000.0f, m);
+        sf_out[w * 25 + lane] = sf;
+    }
+    if (!smr) return;
+    __shared__ float sfs[32];
+    if (lane < 25) sfs[lane] = sf;
+    __syncthreads();
+    for (int k = lane; k < 1024; k += 64) {
+        short v = 0;
+        if (smr[w * 1024 + k] > T.smr_thr) {
+            const float r = round_away(c[k] * sfs[T.band[k]]);
+            // .clamp(I16_MIN_F32, I16_MAX_F32) as i16: f32::clamp passes a NaN through and `as i16` maps it to 0
+            v = (r == r) ? (short)fminf(fmaxf(r, -32768.0f), 32767.0f) : (short)0;
+        }
+        q[w * 1024 + k] = v;
+    }
+}
+
 // serialize_sparse of independent 1024-value vectors into fixed slots (flo_sparse_pack). form 0: the packer wave's own
 // routine - the item form, behind it the block form for vectors with more than 128 non-zeros, behind that the general
 // form for the vectors the block form declines; form 2 starts at the block form, form 1 forces the general form for
@@ -1536,6 +1575,12 @@ int launch_lossy_compact(const LossyArgs &A, hipStream_t s) {
 }
 int launch_mdct_only(const LossyDevTables &T, const float *frames, unsigned long long n, float *out, hipStream_t s) {
     hipLaunchKernelGGL(mdct_only_kernel, dim3((unsigned)n), dim3(64), 0, s, T, frames, n, out);
+    FLO_LAUNCH_CHECK();
+    return 0;
+}
+int launch_quantise_smr(const LossyDevTables &T, const float *coeffs, const float *smr, unsigned long long n, short *q, float *sf,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(quantise_smr_kernel, dim3((unsigned)n), dim3(64), 0, s, T, coeffs, smr, n, q, sf);
     FLO_LAUNCH_CHECK();
     return 0;
 }

@@ -55,6 +55,8 @@ constexpr int kMaxLossyChannels = 8;      // more channels than two take the gen
 int launch_lossy_scan(const LossyArgs &A, hipStream_t s);
 int launch_lossy_compact(const LossyArgs &A, hipStream_t s);
 int launch_mdct_only(const LossyDevTables &T, const float *frames, unsigned long long n, float *out, hipStream_t s);
+int launch_quantise_smr(const LossyDevTables &T, const float *coeffs, const float *smr, unsigned long long n, short *q, float *sf,
+                        hipStream_t s);
 int launch_sparse_only(const short *q, unsigned long long n, uint8_t *slots, uint32_t *sizes, int form, hipStream_t s);
 int launch_pack_streams(const uint8_t *src, const unsigned long long *src_off, const unsigned long long *dst_off,
                         const unsigned long long *sizes, int n_clips, uint8_t *dst, hipStream_t s);

@@ -270,9 +270,16 @@ int flo_lossy_analyze(flo_ctx *ctx, const float *pcm, size_t n_interleaved, uint
  * of the threshold with the reference's own dB-domain f32 expression (a test yardstick, never used by an encode). */
 int flo_lossy_quantize(flo_ctx *ctx, const float *coeffs, size_t num_hops, uint32_t sample_rate, uint8_t channels,
                        float quality, int exact, int16_t *quantized, uint16_t *sf_words);
+/* TransformEncoder::quantize_coefficients as the reference exposes it (lossy/encoder.rs:109-154): n_vec vectors of 1024
+ * coefficients with the caller's own signal-to-mask ratios -> i16 (kept iff smr > the quality's threshold, c * scale factor
+ * rounded half away from zero) and the 25 band scale factors (30000 / band maximum, 1.0 for a silent band) per vector.
+ * smr = NULL: scale factors only (quantized is not written). */
+int flo_lossy_quantize_smr(flo_ctx *ctx, const float *coeffs, const float *smr, size_t n_vec, uint32_t sample_rate, float quality,
+                           int16_t *quantized, float *scale_factors);
 /* serialize_sparse on device: n_vec vectors of 1024 i16 -> bytes; out_off[n_vec+1] prefix offsets.
- * Replaces lossy/encoder.rs:284-314. form = 0: the packer as the encoder runs it (block form for sparse vectors, the
- * general form for the dense ones it declines); form = 1: the general form for every vector (tests compare the two). */
+ * Replaces lossy/encoder.rs:284-314. form = 0: the packer as the encoder runs it (item form up to 128 non-zeros, behind it
+ * the block form, behind that the general form for the dense vectors it declines); form = 1: the general form for every
+ * vector; form = 2: block form, then general (tests compare the three). */
 int flo_sparse_pack(flo_ctx *ctx, const int16_t *q, size_t n_vec, int form, uint8_t *out, size_t out_cap,
                     uint32_t *out_off);
 

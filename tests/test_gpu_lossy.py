@@ -549,3 +549,56 @@ def test_kernel_forms_agree_on_loud_and_lopsided_stereo(ctx, amp):
         b.close()
     for form in (1, 2):
         assert outs[form] == outs[5], form
+
+
+def test_transform_encoder_frame_methods(ctx):
+    """TransformEncoder::{encode_frame, quantize_coefficients, reset} of the mirror class (lossy/encoder.rs:63,109,157), driven the
+    way encode_to_flo drives them (encoder.rs:174-225: 1024 zeros of pre-roll, blocks of 2048 at a hop of 1024): frame by
+    frame the integers and scale words must be what the whole-clip device pass and the oracle produce - also beyond the 65
+    frames of history the mirror keeps for the temporal masking state."""
+    import flo_amd
+    sr, ch, q = 44100, 2, 0.55
+    n = 80 * 1024 + 300
+    pcm = signals.music_like(sr, n, ch, seed=91)
+    o = O.lossy_analyze(pcm, sr, ch, q)
+    g = ctx.lossy_analyze(pcm, sr, ch, q)
+    hops = o["q"].shape[0]
+    padded = np.zeros(((hops + 1) * 1024, ch), np.float32)
+    padded[1024:1024 + n] = pcm.reshape(-1, ch)
+    enc = flo_amd.TransformEncoder(sr, ch, q, ctx)
+    band = O.psy_tables(sr)[1]
+    for h in range(hops):
+        fr = enc.encode_frame(padded[h * 1024:h * 1024 + 2048].reshape(-1))
+        assert fr.block_size == 2048 and fr.num_samples == 1024 and len(fr.coefficients) == ch
+        for c in range(ch):
+            assert np.array_equal(fr.coefficients[c], g["q"][h, c]), (h, c)          # the device's own whole-clip pass, bit for bit
+            assert np.array_equal(fr.scale_words[c], g["sf_words"][h, c]), (h, c)
+            bm = np.array([np.abs(g["coeffs"][h, c][band == b]).max(initial=0.0) for b in range(25)], np.float32)
+            want = np.where(bm > 1e-10, np.float32(30000.0) / np.where(bm > 1e-10, bm, 1).astype(np.float32), np.float32(1.0)).astype(np.float32)
+            assert np.array_equal(fr.scale_factors[c], want), (h, c)                  # 30000 / band_max, IEEE f32
+    stage = dict(coeffs=g["coeffs"], q=g["q"], sf_words=g["sf_words"])
+    compare_lossy_stage(stage, o, sr, tag="encode_frame")                             # and the oracle, within the stage tolerances
+    # reset(): the temporal state is gone - the next frame is encoded like a clip's first
+    enc.reset()
+    first = enc.encode_frame(padded[40 * 1024:40 * 1024 + 2048].reshape(-1))
+    fresh = flo_amd.TransformEncoder(sr, ch, q, ctx).encode_frame(padded[40 * 1024:40 * 1024 + 2048].reshape(-1))
+    assert all(np.array_equal(a, b) for a, b in zip(first.coefficients, fresh.coefficients))
+    # quantize_coefficients with the caller's own signal-to-mask ratios (encoder.rs:109-154)
+    rng = np.random.default_rng(3)
+    coeffs = g["coeffs"][7, 0].copy()
+    coeffs[100] = np.nan
+    smr = rng.uniform(-80, 20, 1024).astype(np.float32)
+    for quality in (0.0, 0.55, 1.0):
+        enc.set_quality(quality)
+        qv, sf = enc.quantize_coefficients(coeffs, smr)
+        t = max(1.0 - quality, 0.001)
+        thr = np.float32(-100.0) if quality >= 0.99 else np.float32(-60.0) * (np.float32(1.0) - np.float32(t) ** np.float32(0.5))
+        bm = np.array([np.nanmax(np.abs(coeffs[band == b]), initial=0.0) for b in range(25)], np.float32)
+        want_sf = np.where(bm > 1e-10, np.float32(30000.0) / np.where(bm > 1e-10, bm, 1).astype(np.float32), np.float32(1.0)).astype(np.float32)
+        assert np.array_equal(sf, want_sf)
+        scaled = (coeffs * want_sf[band]).astype(np.float32)
+        tr = np.trunc(scaled)
+        dd = (scaled - tr).astype(np.float32)                                          # exact
+        r = np.where(np.isnan(scaled), 0, tr + np.trunc(dd + dd))                      # f32::round: half away from zero
+        want_q = np.where(smr > thr, np.clip(r, -32768, 32767), 0).astype(np.int16)
+        assert np.array_equal(qv, want_q), quality
