@@ -29,7 +29,7 @@ EXPORTS = [
     "flo_dist_table_submit", "flo_dist_table_flush", "flo_dist_table_result",
     "flo_stream_create", "flo_stream_destroy", "flo_stream_push", "flo_stream_pending_samples", "flo_stream_pending_frames",
     "flo_stream_next_frame", "flo_stream_flush", "flo_stream_finalize",
-    "flo_analyze", "flo_analysis_metadata",
+    "flo_analyze", "flo_analysis_metadata", "flo_batch_analysis_metadata", "flo_batch_set_bit_depth",
 ]
 
 
@@ -38,7 +38,7 @@ class Analysis(C.Structure):
                 ("avg_loudness", C.c_uint8), ("pad0", C.c_uint8), ("pad1", C.c_uint8), ("hash", C.c_uint8 * 32),
                 ("frequency_peaks", C.c_uint8 * 8), ("energy_profile", C.c_uint8 * 16), ("integrated_lufs", C.c_double),
                 ("length_ms", C.c_uint64), ("loudness_range_lu", C.c_double), ("true_peak_dbtp", C.c_double),
-                ("sample_peak_dbfs", C.c_double)]
+                ("sample_peak_dbfs", C.c_double), ("sum_squares", C.c_float), ("pad2", C.c_uint32)]
 
 
 class ContainerInfo(C.Structure):
@@ -123,6 +123,8 @@ def lib():
     L.flo_dist_stream.restype = vp
     L.flo_ctx_reserve_cus.argtypes = [vp, C.c_int]
     L.flo_ctx_reserve_cus.restype = C.c_int
+    L.flo_batch_analysis_metadata.argtypes = [vp, sz, C.c_uint32, C.POINTER(vp), C.POINTER(sz)]
+    L.flo_batch_set_bit_depth.argtypes = [vp, C.c_uint8]
     L.flo_ctx_upload_path.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.flo_ctx_reserved_cus.argtypes = [vp]
     L.flo_ctx_reserved_cus.restype = C.c_int

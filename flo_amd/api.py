@@ -184,7 +184,8 @@ class Context:
         return dict(peaks=peaks[: a.n_peaks].copy(), hash=bytes(a.hash), duration_ms=a.duration_ms, sample_rate=a.sample_rate,
                     channels=a.channels, frequency_peaks=list(a.frequency_peaks), energy_profile=list(a.energy_profile),
                     avg_loudness=a.avg_loudness, integrated_lufs=a.integrated_lufs, length_ms=a.length_ms,
-                    loudness_range_lu=a.loudness_range_lu, true_peak_dbtp=a.true_peak_dbtp, sample_peak_dbfs=a.sample_peak_dbfs)
+                    loudness_range_lu=a.loudness_range_lu, true_peak_dbtp=a.true_peak_dbtp, sample_peak_dbfs=a.sample_peak_dbfs,
+                    sum_squares=np.float32(a.sum_squares))
 
     def analysis_metadata(self, samples, sample_rate, channels, peaks_per_second=50) -> bytes:
         """add_analysis_data_if_missing(&[], ...): the MessagePack META libflo::encode* build for an empty input META"""
@@ -326,6 +327,15 @@ class Batch:
         t = C.c_uint64()
         self.ctx._chk(self._L.flo_batch_data_bytes(self._h, C.byref(t)))
         return t.value
+
+    def analysis_metadata(self, clip, peaks_per_second=50) -> bytes:
+        """the analysis META of a clip already uploaded into this batch (no second trip over PCIe)"""
+        out, n = C.c_void_p(), C.c_size_t()
+        self.ctx._chk(self._L.flo_batch_analysis_metadata(self._h, clip, peaks_per_second, C.byref(out), C.byref(n)))
+        return self.ctx._take(out, n)
+
+    def set_bit_depth(self, bit_depth: int):
+        self.ctx._chk(self._L.flo_batch_set_bit_depth(self._h, bit_depth))
 
     def fetch(self, clip, metadata=b"") -> bytes:
         out, n = C.c_void_p(), C.c_size_t()
@@ -552,26 +562,38 @@ def decode(data: bytes):
     return default_context().decode(data)
 
 
-def _with_analysis(samples, sample_rate, channels, metadata):
-    """lib.rs:105-111: `add_analysis_data_if_missing(&metadata.unwrap_or_default(), samples, sr, ch, 50)`"""
+def _encode_analysed(mode, samples, sample_rate, channels, quality_or_level, bit_depth, metadata) -> bytes:
+    """what the three free functions share (lib.rs:97-206): `add_analysis_data_if_missing(&metadata.unwrap_or_default(), samples,
+    sr, ch, 50)`, then the encoder - on ONE copy of the samples: uploaded once, analysed on the device, encoded from there"""
     from . import meta as _meta
-    an = default_context().analysis_metadata(samples, sample_rate, channels, 50)
-    return _meta.merge_analysis(metadata or b"", an)
+    ctx = default_context()
+    p = _f32(samples)
+    b = Batch(ctx, mode, [p.size], sample_rate, channels, quality_or_level)
+    try:
+        b.upload(0, p)
+        m = _meta.merge_analysis(metadata or b"", b.analysis_metadata(0, 50))
+        if mode == MODE_LOSSLESS:
+            b.set_bit_depth(bit_depth)
+        b.encode(0)
+        b.sync()
+        return b.fetch(0, m)
+    finally:
+        b.close()
 
 
 def encode(samples, sample_rate, channels, bit_depth, metadata=None) -> bytes:
     """libflo::encode (lib.rs:97-117): analysis metadata first (waveform peaks, spectral fingerprint, EBU R128 loudness,
     length), then the lossless encoder at level 5"""
-    return Encoder(sample_rate, channels, bit_depth).encode(samples, _with_analysis(samples, sample_rate, channels, metadata))
+    return _encode_analysed(MODE_LOSSLESS, samples, sample_rate, channels, 5, bit_depth, metadata)
 
 
 def encode_lossy(samples, sample_rate, channels, _bit_depth, quality: int, metadata=None) -> bytes:
     """libflo::encode_lossy (lib.rs:135-166): quality level 0-4 -> 0.0/0.35/0.55/0.75/1.0"""
     q = {0: 0.0, 1: 0.35, 2: 0.55, 3: 0.75}.get(int(quality), 1.0)
-    return TransformEncoder(sample_rate, channels, q).encode_to_flo(samples, _with_analysis(samples, sample_rate, channels, metadata))
+    return _encode_analysed(MODE_LOSSY, samples, sample_rate, channels, q, 16, metadata)
 
 
 def encode_with_bitrate(samples, sample_rate, channels, _bit_depth, target_bitrate_kbps, metadata=None) -> bytes:
     """libflo::encode_with_bitrate (lib.rs:181-206)"""
     q = QualityPreset.from_bitrate(target_bitrate_kbps, sample_rate, channels).as_f32()
-    return TransformEncoder(sample_rate, channels, q).encode_to_flo(samples, _with_analysis(samples, sample_rate, channels, metadata))
+    return _encode_analysed(MODE_LOSSY, samples, sample_rate, channels, q, 16, metadata)

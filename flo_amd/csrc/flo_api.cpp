@@ -2331,9 +2331,10 @@ float max_rust(float a, float b) {
 }
 }  // namespace
 
-extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, uint8_t ch, uint32_t pps, float *peaks,
-                           size_t peaks_cap, flo_analysis *out) {
-    if (!c || !out || (n && !pcm) || !ch || !sr || !pps) return c ? fail(c, FLO_ERR_ARG, "flo_analyze: bad argument") : FLO_ERR_ARG;
+// pcm_dev: the samples are already on the device (a batch's clip): nothing is staged
+static int analyze_impl(flo_ctx *c, const float *pcm, const float *pcm_dev, size_t n, uint32_t sr, uint8_t ch, uint32_t pps, float *peaks,
+                        size_t peaks_cap, flo_analysis *out) {
+    if (!c || !out || (n && !pcm && !pcm_dev) || !ch || !sr || !pps) return c ? fail(c, FLO_ERR_ARG, "flo_analyze: bad argument") : FLO_ERR_ARG;
     memset(out, 0, sizeof *out);
     out->sample_rate = sr;
     out->channels = ch;
@@ -2402,8 +2403,36 @@ extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, 
         A.n_seg = (unsigned)((longest + A.seg_frames - 1) / A.seg_frames);
         if (A.n_seg == 0) A.n_seg = 1;
     }
+    // clips beyond one exact segment: two passes over short segments with the filter state handed over exactly
+    // (analysis_kernels.hip, "K-weighting, long clips"); FLO_ANALYSIS_EXACT=1 keeps the one-lane walk (diagnostic)
+    A.fast = (frames > 65536 && A.hop && ch <= 64 && !getenv("FLO_ANALYSIS_EXACT")) ? 1u : 0u;
+    // segment length: two walks of L frames (150 ns per frame) against a scan over frames / L segments (35 ns each):
+    // the power of two next to sqrt(frames / 8), between 256 and 2048
+    A.kseg_frames = 256;
+    while (A.kseg_frames < 2048 && (uint64_t)A.kseg_frames * A.kseg_frames * 8 < frames) A.kseg_frames *= 2;
+    A.n_kseg = (unsigned)((frames + A.kseg_frames - 1) / A.kseg_frames);
+    A.kq = A.hop ? A.kseg_frames / A.hop + 2 : 1;
+    if (A.fast) {
+        // M^L: the homogeneous system (x = 0) walked L steps from each unit state, in the kernels' own arithmetic
+        for (int col = 0; col < 4; col++) {
+            double v[4] = {0, 0, 0, 0};
+            v[col] = 1.0;
+            for (unsigned i = 0; i < A.kseg_frames; i++) {
+                const double y = v[0];
+                const double n1 = -A.shelf[3] * y + v[1], n2 = -A.shelf[4] * y;
+                const double y2 = A.hp[0] * y + v[2];
+                const double m1 = A.hp[1] * y - A.hp[3] * y2 + v[3], m2 = A.hp[2] * y - A.hp[4] * y2;
+                v[0] = n1, v[1] = n2, v[2] = m1, v[3] = m2;
+            }
+            for (int r = 0; r < 4; r++) A.kpow[4 * r + col] = v[r];
+        }
+    }
     A.sq_seg = 1u << 16;
     A.n_sq_seg = (unsigned)((n + A.sq_seg - 1) / A.sq_seg);
+    // beyond one segment the sum of squares is chained chunk by chunk so that it IS the sequential f32 sum (analysis_kernels.hip)
+    A.sq_exact = n > A.sq_seg ? 1u : 0u;
+    A.n_sq_chunks = (n + 1023) / 1024;
+    if (A.sq_exact) A.n_sq_seg = 1;
     {   // compute_true_peak's filter (ebu_r128.rs:117-140): 49-tap Hann-windowed sinc, designed at 4 fs, unit sum
         const double oversample_rate = (double)sr * 4.0, cutoff = (double)sr * 0.45, center = 24.0;
         double sum = 0.0;
@@ -2442,23 +2471,26 @@ extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, 
     // device buffers: pcm | results
     DevMem d_pcm, d_res, d_cvs;
     QuiesceOnExit quiesce_d_pcm(c);
-    HIPCHK(c, pool_alloc(&d_pcm.p, n * 4 + 64));
+    if (!pcm_dev) HIPCHK(c, pool_alloc(&d_pcm.p, n * 4 + 64));
     const size_t o_peaks = 0, o_sumsq = o_peaks + (((size_t)A.n_peaks * 4 + 15) & ~(size_t)15),
                  o_pk = o_sumsq + (((size_t)A.n_sq_seg * 4 + 15) & ~(size_t)15), o_blocks = o_pk + 16,
                  o_tw = o_blocks + (((size_t)ch * A.n_blocks * 16 + 15) & ~(size_t)15), o_band = o_tw + sizeof tw, o_bin = o_band + 3 * 16 * 4,
-                 res_bytes = o_bin + 3 * 8 * 4;
+                 o_kq = (o_bin + 3 * 8 * 4 + 15) & ~(size_t)15, o_kst = o_kq + (A.fast ? (size_t)ch * A.n_kseg * A.kq * 8 : 0),
+                 o_sqd = o_kst + (A.fast ? (size_t)ch * A.n_kseg * 32 : 0), o_sqr = o_sqd + (A.sq_exact ? (A.n_sq_chunks + 1) * 8 : 0),
+                 o_pkp = o_sqr + (A.sq_exact ? A.n_sq_chunks * 64 : 0),
+                 res_bytes = o_pkp + (A.fast ? ((((n + ch - 1) / ch + 2047) / 2048) * ch * 16) : 0);
     HIPCHK(c, pool_alloc(&d_res.p, res_bytes + 64));
     HIPCHK(c, pool_alloc(&d_cvs.p, (2 * A.n_chunks + 1) * 32 + 64));
     int rc = ctx_stager(c);
     if (rc != FLO_OK) return rc;
-    {
+    if (!pcm_dev) {
         std::vector<UploadSeg> segs{{d_pcm.p, pcm, n * 4}};
         std::string err;
         if (stager_upload(c->stager, segs, c->stream, err) != 0) return fail(c, FLO_ERR_DEVICE, err);
     }
-    HIPCHK(c, hipMemsetAsync(d_res.p, 0, res_bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_res.p, 0, o_kst, c->stream));   // (what lies behind is fully written by its kernels)
     HIPCHK(c, hipMemcpyAsync((char *)d_res.p + o_tw, tw, sizeof tw, hipMemcpyHostToDevice, c->stream));
-    A.pcm = d_pcm.as<float>();
+    A.pcm = pcm_dev ? pcm_dev : d_pcm.as<float>();
     char *rb = (char *)d_res.p;
     A.peaks = (float *)(rb + o_peaks);
     A.sumsq_part = (float *)(rb + o_sumsq);
@@ -2467,15 +2499,20 @@ extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, 
     A.fft_tw = (const float *)(rb + o_tw);
     A.band_sqrt = (float *)(rb + o_band);
     A.peak_bin = (unsigned int *)(rb + o_bin);
+    A.kqpart = (double *)(rb + o_kq);
+    A.kstate = (double *)(rb + o_kst);
+    A.sq_dsum = (double *)(rb + o_sqd);
+    A.sq_rec = (double *)(rb + o_sqr);
+    A.peak_part = (double *)(rb + o_pkp);
     A.cvs = d_cvs.as<unsigned int>();
     rc = timed_launch(c, "analysis", [&] { return launch_analysis(A, c->stream); });
     if (rc != FLO_OK) {
         hipStreamSynchronize(c->stream);
         return rc;
     }
-    std::vector<uint8_t> res(res_bytes);
+    std::vector<uint8_t> res(o_kst);   // (what lies behind - filter states, the chunk records of the sum of squares - stays on the device)
     uint32_t root[8];
-    HIPCHK(c, hipMemcpyAsync(res.data(), d_res.p, res_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(res.data(), d_res.p, o_kst, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(root, d_cvs.as<unsigned int>() + 2 * A.n_chunks * 8, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // waveform peaks: normalise by the largest (analysis.rs:103-109)
@@ -2510,6 +2547,10 @@ extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, 
         memcpy(out->frequency_peaks, pk8, 8);
         float sumsq = 0.f;   // the segments' partial sums, in order (one segment: the reference's own sequential sum)
         for (unsigned i = 0; i < A.n_sq_seg; i++) sumsq = i ? sumsq + ((const float *)(res.data() + o_sumsq))[i] : ((const float *)(res.data() + o_sumsq))[0];
+        out->sum_squares = sumsq;
+        if (A.sq_exact && getenv("FLO_TRACE"))
+            fprintf(stderr, "[analysis] sum of squares: %llu chunks, %g walked sample by sample\n", (unsigned long long)A.n_sq_chunks,
+                    (double)((const float *)(res.data() + o_sumsq))[1]);
         const float rms = sumsq / (float)n;
         float v = -20.0f * log10f(rms + 1e-10f);
         if (v == v) v = v < -60.0f ? -60.0f : (v > 0.0f ? 0.0f : v);
@@ -2519,6 +2560,28 @@ extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, 
     // peaks (ebu_r128.rs:211-355)
     {
         const double *part = (const double *)(res.data() + o_blocks);
+        std::vector<double> fastpart;
+        if (A.fast) {
+            // the segments' shares of every 100 ms quantum, added in segment order; a block is its four quanta, in order
+            const uint64_t nq = (frames + A.hop - 1) / A.hop;
+            const double *kq = (const double *)(res.data() + o_kq);
+            std::vector<double> quanta((size_t)ch * nq, 0.0);
+            for (unsigned cc = 0; cc < ch; cc++)
+                for (uint64_t sg = 0; sg < A.n_kseg; sg++) {
+                    const uint64_t f0 = sg * A.kseg_frames, f1 = std::min<uint64_t>(f0 + A.kseg_frames, frames);
+                    if (f1 <= f0) continue;
+                    const uint64_t q0 = f0 / A.hop, q1 = (f1 - 1) / A.hop;
+                    for (uint64_t q = q0; q <= q1; q++) quanta[(size_t)cc * nq + q] += kq[((size_t)cc * A.n_kseg + sg) * A.kq + (q - q0)];
+                }
+            fastpart.assign((size_t)ch * A.n_blocks * 2, 0.0);
+            for (unsigned cc = 0; cc < ch; cc++)
+                for (unsigned k = 0; k < A.n_blocks; k++) {
+                    double e = 0.0;
+                    for (uint64_t q = k; q < (uint64_t)k + 4 && q < nq; q++) e += quanta[(size_t)cc * nq + q];
+                    fastpart[((size_t)cc * A.n_blocks + k) * 2] = e;
+                }
+            part = fastpart.data();
+        }
         std::vector<double> en(A.n_blocks);
         for (unsigned k = 0; k < A.n_blocks; k++) {
             double e = 0.0;
@@ -2573,15 +2636,20 @@ extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, 
     return FLO_OK;
 }
 
-extern "C" int flo_analysis_metadata(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, uint8_t ch, uint32_t pps,
-                                     uint8_t **out, size_t *out_len) {
+extern "C" int flo_analyze(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, uint8_t ch, uint32_t pps, float *peaks,
+                           size_t peaks_cap, flo_analysis *out) {
+    return analyze_impl(c, pcm, nullptr, n, sr, ch, pps, peaks, peaks_cap, out);
+}
+
+static int analysis_metadata_impl(flo_ctx *c, const float *pcm, const float *pcm_dev, size_t n, uint32_t sr, uint8_t ch, uint32_t pps,
+                                  uint8_t **out, size_t *out_len) {
     if (!c || !out || !out_len) return FLO_ERR_ARG;
     *out = nullptr;
     *out_len = 0;
     if (!ch || !sr || !pps) return fail(c, FLO_ERR_ARG, "flo_analysis_metadata: bad argument");
     std::vector<float> peaks(n / ch + 16);
     flo_analysis an;
-    int rc = flo_analyze(c, pcm, n, sr, ch, pps, peaks.data(), peaks.size(), &an);
+    int rc = analyze_impl(c, pcm, pcm_dev, n, sr, ch, pps, peaks.data(), peaks.size(), &an);
     if (rc != FLO_OK) return rc;
     Mp m, fp;
     m.b.push_back(0x84);
@@ -2628,5 +2696,20 @@ extern "C" int flo_analysis_metadata(flo_ctx *c, const float *pcm, size_t n, uin
     memcpy(p, m.b.data(), m.b.size());
     *out = p;
     *out_len = m.b.size();
+    return FLO_OK;
+}
+extern "C" int flo_analysis_metadata(flo_ctx *c, const float *pcm, size_t n, uint32_t sr, uint8_t ch, uint32_t pps,
+                                     uint8_t **out, size_t *out_len) {
+    return analysis_metadata_impl(c, pcm, nullptr, n, sr, ch, pps, out, out_len);
+}
+// the same from a clip that is already on the device (uploaded into a batch that is about to be encoded): libflo::encode*
+// analyse and encode the same samples (lib.rs:105-116), and they cross PCIe once
+extern "C" int flo_batch_analysis_metadata(flo_batch *b, size_t clip, uint32_t pps, uint8_t **out, size_t *out_len) {
+    if (!b || clip >= b->n_clips) return FLO_ERR_ARG;
+    return analysis_metadata_impl(b->ctx, nullptr, b->n_il[clip] ? b->d_pcm + b->clip_off[clip] : nullptr, b->n_il[clip], b->sr, b->ch, pps, out, out_len);
+}
+extern "C" int flo_batch_set_bit_depth(flo_batch *b, uint8_t bit_depth) {
+    if (!b) return FLO_ERR_ARG;
+    b->bit_depth = bit_depth;   // (echoed into the header like flo_encode_lossless's argument: writer.rs:146)
     return FLO_OK;
 }

@@ -214,11 +214,22 @@ typedef struct flo_analysis {
     /* the rest of compute_ebu_r128_loudness (ebu_r128.rs:182-355; not part of the META chunk, printed by the CLI's
      * `analysis` command like reflo's): range of the gated block loudness, the 49-tap "true peak", the sample peak */
     double loudness_range_lu, true_peak_dbtp, sample_peak_dbfs;
+    /* the f32 accumulator avg_loudness is derived from (analysis.rs:338: the sequential sum of s * s over all samples),
+     * bit for bit the reference's value at any length; exposed for the tests */
+    float sum_squares;
+    uint32_t pad2;
 } flo_analysis;
 int flo_analyze(flo_ctx *ctx, const float *pcm, size_t n_interleaved, uint32_t sample_rate, uint8_t channels,
                 uint32_t peaks_per_second, float *peaks, size_t peaks_cap, flo_analysis *out);
 int flo_analysis_metadata(flo_ctx *ctx, const float *pcm, size_t n_interleaved, uint32_t sample_rate, uint8_t channels,
                           uint32_t peaks_per_second, uint8_t **out, size_t *out_len);
+/* the same for a clip that already sits in a batch (after flo_batch_upload): libflo::encode* analyse and encode the SAME
+ * samples (lib.rs:105-116), so the free functions upload once, analyse on the device copy, then encode it:
+ *   flo_batch_create(1 clip); flo_batch_upload; flo_batch_analysis_metadata -> META (merge with the caller's);
+ *   flo_batch_set_bit_depth (lossless); flo_batch_encode; flo_batch_sync; flo_batch_fetch(meta) */
+int flo_batch_analysis_metadata(flo_batch *b, size_t clip, uint32_t peaks_per_second, uint8_t **out, size_t *out_len);
+/* the bit depth a lossless batch's files declare (16 unless set; flo_encode_lossless's argument) */
+int flo_batch_set_bit_depth(flo_batch *b, uint8_t bit_depth);
 
 /* ---- streaming encoder: StreamingEncoder of libflo/src/streaming/encoder.rs:6-257 -----------------------------
  * Samples are pushed (interleaved f32); every complete one-second frame is encoded losslessly - all frames a push

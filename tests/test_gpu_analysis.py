@@ -104,3 +104,57 @@ def test_long_clips_in_segments_agree_with_the_sequential_oracle(ctx):
         for k in ("integrated_lufs", "loudness_range_lu", "true_peak_dbtp", "sample_peak_dbfs"):
             assert abs(a[k] - o[k]) <= 1e-9 * max(1.0, abs(o[k])), (sr, k, a[k], o[k])
         assert ctx.analysis_metadata(pcm, sr, ch, 50) == O.analysis_metadata(pcm, sr, ch, 50)
+
+
+def _seq_sum_squares(x):
+    """analysis.rs:338 literally: one f32 accumulator, sample after sample (numpy's cumsum is that recurrence)"""
+    x = np.asarray(x, np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        return np.cumsum(x * x, dtype=np.float32)[-1] if x.size else np.float32(0)
+
+
+def _sumsq_cases():
+    rng = np.random.default_rng(11)
+    yield "music 60 s stereo", signals.music_like(44100, 60 * 44100, 2, seed=5)
+    yield "noise 2.7 M samples, odd length", (rng.uniform(-1, 1, 2_700_001) * 0.3).astype(np.float32)
+    yield "constant 0.5: every addition a tie for a while", np.full(1_500_000, 0.5, np.float32)
+    yield "constant 2^-7: exact powers of two", np.full(900_000, 2.0 ** -7, np.float32)
+    q = np.concatenate([(rng.uniform(-1, 1, 1_000_000) * 1e-4), rng.uniform(-1, 1, 300_000) * 0.9, rng.uniform(-1, 1, 700_000) * 1e-3]).astype(np.float32)
+    yield "quiet, loud, quiet", q
+    yield "loud first", q[::-1].copy()
+    t = (rng.uniform(-1, 1, 400_000) * 0.2).astype(np.float32)
+    t[123_457] = np.inf
+    yield "an infinite sample", t
+    t2 = t.copy(); t2[123_457] = np.nan
+    yield "a NaN sample", t2
+    yield "denormal-small samples", (rng.uniform(-1, 1, 300_000) * 1e-20).astype(np.float32)
+    big = (rng.uniform(-1, 1, 200_000) * 3e18).astype(np.float32)
+    yield "squares that overflow the accumulator", big
+    z = np.zeros(500_000, np.float32); z[400_000:] = 0.25
+    yield "zeros, then a step", z
+    g = (rng.standard_normal(1_200_000) * np.exp(rng.uniform(-12, 0, 1_200_000))).astype(np.float32)
+    yield "terms across sixteen binades", g
+
+
+@pytest.mark.parametrize("name,x", list(_sumsq_cases()), ids=[c[0] for c in _sumsq_cases()])
+def test_sum_of_squares_is_the_sequential_f32_sum_at_any_length(ctx, name, x):
+    # beyond one segment the device chains chunks of 1024 samples (integer increments per binade) instead of adding partial
+    # sums: the accumulator must come out bit for bit as the reference's loop leaves it, and avg_loudness with it
+    a = ctx.analyze(x, 44100, 2 if x.size % 2 == 0 else 1, 50)
+    want = _seq_sum_squares(x)
+    got = np.float32(a["sum_squares"])
+    assert got.view(np.uint32) == want.view(np.uint32) or (np.isnan(got) and np.isnan(want)), (name, got, want)
+    fp = O.spectral_fingerprint(x, 2 if x.size % 2 == 0 else 1, 44100)
+    assert a["avg_loudness"] == fp["avg_loudness"]
+
+
+def test_long_clip_loudness_two_pass_state_hand_over(ctx):
+    # beyond 65 536 frames the K-weighting runs as two passes over 2048-frame segments with the filter state handed over
+    # through the 4 x 4 transition matrix; 3 minutes, ragged length, several rates and channel counts
+    for sr, ch, secs in ((44100, 2, 180.0), (48000, 1, 61.7), (8000, 3, 33.3), (192000, 2, 4.1)):
+        pcm = signals.music_like(sr, int(sr * secs) + 13, ch, seed=int(secs))
+        a = ctx.analyze(pcm, sr, ch, 50)
+        o = O.loudness_metrics(pcm, ch, sr)
+        for k in ("integrated_lufs", "loudness_range_lu", "true_peak_dbtp", "sample_peak_dbfs"):
+            assert abs(a[k] - o[k]) <= 1e-9 * max(1.0, abs(o[k])), (sr, ch, k, a[k], o[k])
+        assert ctx.analysis_metadata(pcm, sr, ch, 50) == O.analysis_metadata(pcm, sr, ch, 50)
