@@ -47,7 +47,7 @@ def host_cores():
     return n
 
 
-PROFILE_SUMMARY = "profiles/r03_profile_summary.json"
+PROFILE_SUMMARY = "profiles/r04_profile_summary.json"
 
 
 def kernel_source_sha():

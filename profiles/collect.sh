@@ -8,7 +8,7 @@ tag=${1:-r02}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-# --no-shard: every lossy_chain2x launch of this pass is the headline workload, so the CSV's average is comparable
+# --no-shard: every lossy_chain2q launch of this pass is the headline workload, so the CSV's average is comparable
 # with the bench line's kernel_ms
 BENCH="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-shard"
 rocprofv3 --kernel-trace --stats -d $out/stats -o run --output-format csv -- python3 $BENCH > $out/stats.log 2>&1

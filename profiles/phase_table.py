@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static per-phase instruction counts of lossy_chain2x_kernel from a -DFLO_MARKS assembly listing.
+"""Static per-phase instruction counts of the transform wave of lossy_chain2q_kernel from a -DFLO_MARKS assembly listing.
 
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -ffp-contract=off -Iinclude -DFLO_MARKS \
         -S --cuda-device-only -o /tmp/lk_marks.s flo_amd/csrc/lossy_kernels.hip
@@ -31,7 +31,7 @@ def classify(op):
 
 def main():
     path = sys.argv[1]
-    want = sys.argv[2] if len(sys.argv) > 2 else "lossy_chain2x_kernelILb0ELj48574ELb0EE"
+    want = sys.argv[2] if len(sys.argv) > 2 else "lossy_chain2q_kernelILb0ELj48574ELb0EE"
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and want in l and ":" in l.split(";")[0])
     end = next(i for i in range(start, len(lines)) if ".size" in lines[i] and want in lines[i])
@@ -55,9 +55,13 @@ def main():
         if cur not in order:
             order.append(cur)
     # instructions after marker X and before marker Y belong to phase Y
-    names = {"frame_begin": "fold", "fold_done": "prefetch", "prefetch_done": "fft512 x2", "fft_done": "post-rotation + transpose",
-             "postrot_done": "band_stats_2", "bandstats_done": "masking", "mask_done": "quantise_2", "quant_done": "hand-over",
-             "frame_end": "(between frames / loop)"}
+    # (round 4: the frame loop is software-pipelined - the next frame's fold runs at the end of a frame, the masking pass of the
+    # previous frame inside the FFT, behind the first exchange)
+    # what FOLLOWS each marker (round 4: the frame loop is software-pipelined - the next frame's fold runs at the end of a
+    # frame, the masking pass of the previous frame inside the FFT, behind the first exchange)
+    names = {"frame_begin": "prefetch (16 loads), masking rows", "prefetch_done": "fft512 x2 + masking pass (prev. frame)",
+             "fft_done": "post-rotation + transpose", "postrot_done": "band_stats_2",
+             "bandstats_done": "fold of the next frame (a)", "frame_end": "fold of the next frame (b), loop"}
     print(f"{'phase':32s} {'VALU':>6s} {'SALU':>6s} {'LDS':>5s} {'VMEM':>5s} {'wait':>5s}   (per stereo frame, mean of the two unrolled bodies)")
     tot = collections.Counter()
     for ph in order:
@@ -65,7 +69,7 @@ def main():
         nm = names.get(ph, ph)
         div = 1 if ph.startswith("pre (") else 2
         row = {k: c[k] / div for k in ("valu", "salu", "lds", "vmem", "wait")}
-        if not ph.startswith("pre (") and ph != "frame_end":
+        if not ph.startswith("pre ("):
             for k, v in row.items():
                 tot[k] += v
         print(f"{nm:32s} {row['valu']:6.0f} {row['salu']:6.0f} {row['lds']:5.0f} {row['vmem']:5.0f} {row['wait']:5.0f}")
