@@ -346,6 +346,10 @@ def main():
                      "bytes_named": sum(sum(t[0]) for t in tab)}
 
     if rank != 0:
+        if gather is not None:
+            gather.close()
+        batch.close()
+        ctx.close()
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -591,6 +595,8 @@ def main():
         out["cpu_baseline"]["all_cores"] = {"value": round(reps * args.cpu_clips * n_il / d3 / 1e6, 3), "unit": "Msamples/s",
                                             "cores": cores, "sample": f"{reps * args.cpu_clips} clips, one per pool thread, {d3:.1f} s"}
     print(json.dumps(out))
+    if gather is not None:
+        gather.close()      # (before the context it was made on)
     batch.close()
     ctx.close()
     if dist is not None:

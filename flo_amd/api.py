@@ -82,6 +82,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for g in list(getattr(self, "_dists", ())):   # communicators made on this context go first (flo_dist_destroy uses it)
+                g.close()
             for b in list(self._batches):
                 b.close()
             self._L.flo_ctx_destroy(self._h)

@@ -64,6 +64,9 @@ class NativeGather:
         h = C.c_void_p()
         ctx._chk(self._L.flo_dist_create(ctx._h, id_bytes, rank, world, root, C.byref(h)))
         self._h = h
+        if not hasattr(ctx, "_dists"):
+            ctx._dists = set()
+        ctx._dists.add(self)
 
     def submit(self, batch):
         self.ctx._chk(self._L.flo_dist_gather_submit(self._h, batch._h))
@@ -101,6 +104,7 @@ class NativeGather:
         if getattr(self, "_h", None):
             self._L.flo_dist_destroy(self._h)
             self._h = None
+            getattr(self.ctx, "_dists", set()).discard(self)
 
     def __del__(self):
         try:
