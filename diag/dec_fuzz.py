@@ -1,7 +1,8 @@
 """Randomised differential test of the device decoders on damaged files: whatever the oracle decoder makes of a file
 (an error, or PCM), the device decoder must make the same (lossless: same integers; lossy: within 2e-6)."""
 import sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, flo_amd, flofile, signals
 from oracle import oracle as O
 ctx = flo_amd.Context(0)

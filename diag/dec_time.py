@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, flo_amd
 ctx = flo_amd.Context(0)
 sr, ch, n = 44100, 2, 1250

@@ -1,6 +1,8 @@
-"""Soak: the lock-step stereo, three-wave and two-wave chain kernels against the frame-parallel form, many times, several batch shapes."""
+"""Soak: the lock-step stereo chain (form 5) and the one-wave-per-channel chain (form 1) against the frame-parallel form, many
+times, several batch shapes and qualities (q = 0.2 / 0.55 / 0.8 / 1.0: sparse frames, item form with and without the block form behind it, dense frames)."""
 import sys
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, flo_amd
 ctx = flo_amd.Context(0)
 sr, ch = 44100, 2
@@ -12,12 +14,12 @@ def packed(b, form):
     return buf[: offs[-1]].clone()
 bad = 0
 for shape in ([sr * 10 * ch] * 1250, [sr * 3 * ch] * 2500, [(1000 + 977 * i) * ch for i in range(700)], [sr * 30 * ch] * 300):
-    for q in (0.55, 1.0):
+    for q in (0.2, 0.55, 0.8, 1.0):
         b = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, shape, sr, ch, q)
         b.fill_synthetic(seed=1234, clip_id0=7)
         ref = packed(b, 2)
-        for it in range(12):
-            for form in (4, 3, 1):
+        for it in range(10):
+            for form in (5, 5, 1):
                 got = packed(b, form)
                 if got.shape != ref.shape or not torch.equal(got, ref):
                     bad += 1
