@@ -1437,6 +1437,18 @@ static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes,
         tile0[i + 1] = tile0[i] + nt;
         if (nt > max_tiles) max_tiles = nt;
     }
+    if (getenv("FLO_TRACE")) {
+        size_t lpc = 0, lpc8 = 0, fixed = 0, other = 0, ser = 0;
+        for (size_t i = 0; i < w.chs.size(); i++) {
+            const LlChannelDev &d = w.chs[i];
+            if (serial[i]) ser++;
+            else if (d.n_coeffs && d.len) (d.n_coeffs <= 8 ? lpc8 : lpc)++;
+            else if (d.len && d.shift_bits >= 128) fixed++;
+            else other++;
+        }
+        fprintf(stderr, "[flo] ll decode: %zu wrappers: LPC order <= 8 %zu, order 9..12 %zu, fixed %zu, raw/silent/empty %zu, serial %zu\n", w.chs.size(), lpc8,
+                lpc, fixed, other, ser);
+    }
     if ((rc = upload(c, d_t0, tile0)) || (rc = upload(c, d_ser, serial))) return rc;
     const size_t tiles = tile0.back();
     hipError_t e = pool_alloc(&d_scr.p, w.scratch ? w.scratch * sizeof(int) : 16);

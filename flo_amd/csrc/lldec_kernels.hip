@@ -14,17 +14,19 @@
 //                    reads) and notes, per tile, the real entry state and the index of its first code;
 //   3. rice_decode : a lane per tile walks its tile once more from the now known entry and writes the residuals;
 //   4. predict     : the LPC recurrence is the one truly serial piece (the shift rounds, so it is no linear scan).
-//                    One wavefront per wrapper runs it in transposed form: lane l of a 64-sample block accumulates the
-//                    prediction of sample l, every finished sample is broadcast with v_readlane and multiplied into
-//                    all later accumulators at once by one v_fma_f64 whose coefficient register is the tap vector
-//                    rotated to that step (64 rotations kept in VGPRs), so a sample costs floor + 2 readlane + fma.
+//                    It runs in transposed form, four wrappers per wavefront (one per row of sixteen lanes): lane l
+//                    of a 16-sample block accumulates the prediction of sample l, and a finished sample reaches the
+//                    later accumulators of its row through the DPP operand of one v_fmac_f64 (row_newbcast) whose
+//                    coefficient register is the tap vector rotated to that step: a sample costs floor + fmac,
+//                    21 cycles (diag/dpp_step_rate.hip; the 64-lane form of rounds 2 - 3 paid floor + 2 readlane +
+//                    fma, 30 cycles, for ONE wrapper per wavefront). See predict_rows.
 //                    Doubles are exact here: the host only admits wrappers with sum |coef| < 2^21 and shift <= 20, so
 //                    every partial sum (residual included) is a multiple of 2^-shift whose numerator stays below
 //                    2^31 * 2^20 + 2^21 * 2^31 < 2^53. The reference's i32 wrap-around cannot be followed
 //                    that way; a sample that leaves the i32 range flags the wrapper and the serial kernel redoes it
 //                    (as it does wrappers with k > 14, a 256-ones escape, or larger coefficients).
 //                    Fixed predictors of order 1..4 are `order` wrapping prefix sums (decoder.rs:186-266 read as
-//                    difference equations, warm-up included); raw and silent wrappers are copies.
+//                    difference equations, warm-up included), all taken in one sweep; raw and silent wrappers are copies.
 // Zero padding stands in for the reader's end-of-stream rules: ones up to the end then a (virtual) 0, remainder bits
 // past the end read as 0, and a value that starts past the end is 0 (rice_chain clears those samples).
 #include "decode_kernels.hpp"
@@ -274,20 +276,22 @@ __global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ 4. predictors
-__device__ __forceinline__ int wave_scan_add(int v, int lane) {   // inclusive, wrapping
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(v, d, 64);
-        if (lane >= d) v = (int)((unsigned)v + (unsigned)o);
-    }
+// inclusive wrapping sum over the 64 lanes, in the DPP network: four shifts inside the rows of sixteen, then lane 15 of
+// row 0 / 2 into rows 1 / 3 and lane 31 into the upper half
+__device__ __forceinline__ unsigned wave_scan_add_dpp(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1, 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2, 3
     return v;
 }
 
-__global__ __launch_bounds__(64) void ll_predict_kernel(LlParArgs A) {
-    __shared__ double cs[64];
-    const unsigned chi = blockIdx.x;
+// One wrapper by the whole wavefront: fixed predictors, raw and silent wrappers, LPC wrappers without a recurrence to run
+// (ll_predict_kernel takes the others four at a time in rows, see predict_rows).
+__device__ __noinline__ void predict_one(const LlParArgs &A, const unsigned chi, const int lane, double *cs) {
     if (A.serial[chi]) return;
-    const int lane = (int)threadIdx.x;
     const LlChannelDev c = A.ch[chi];
     int *r = A.scratch + c.out_off;
     const uint32_t n = c.samples;
@@ -298,23 +302,46 @@ __global__ __launch_bounds__(64) void ll_predict_kernel(LlParArgs A) {
         // D^m_i = D^m_(i-1) + D^(m+1)_i: for m = order-1 .. 0 an inclusive wrapping prefix sum over a[m..]
         const int order = c.shift_bits - 128;
         if (order < 1 || order > 4) return;   // order 0, and unknown orders, copy the residuals
-        for (int m = order - 1; m >= 0; m--) {
-            int carry = 0;
-            for (uint32_t base = (uint32_t)m; base < n; base += 256u) {
-                int v[4];
+        // All `order` sums in one sweep: a tile of 256 samples (four consecutive ones per lane) takes sum m = order - 1
+        // down to 0 in registers - a lane's four serially, the lanes' totals by a DPP scan - with one carry per sum
+        // from tile to tile; the plane is read and written once (it was `order` sweeps of shuffle scans: 2 ms for a
+        // one-second frame at 96 kHz, the longest thing the decode did).
+        int carry[4] = {0, 0, 0, 0};
+        for (uint32_t base4 = 0; base4 < n; base4 += 1024u) {   // four tiles' loads in flight together
+            int v[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t i = base + 64u * j + lane;
-                    v[j] = i < n ? r[i] : 0;
+                    const uint32_t i = base4 + 256u * (uint32_t)q + 4u * (uint32_t)lane + (uint32_t)j;
+                    v[q][j] = i < n ? r[i] : 0;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t i = base + 64u * j + lane;
-                    const int s = (int)((unsigned)wave_scan_add(v[j], lane) + (unsigned)carry);
-                    if (i < n) r[i] = s;
-                    carry = __builtin_amdgcn_readlane(s, 63);
+            for (int q = 0; q < 4; q++) {
+                const uint32_t i0 = base4 + 256u * (uint32_t)q + 4u * (uint32_t)lane;
+#pragma unroll
+                for (int m = 3; m >= 0; m--) {
+                    if (m < order) {   // (uniform)
+                        unsigned a[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) a[j] = i0 + (uint32_t)j >= (uint32_t)m ? (unsigned)v[q][j] : 0u;   // sum m starts at sample m
+                        a[1] += a[0], a[2] += a[1], a[3] += a[2];
+                        const unsigned tot = wave_scan_add_dpp(a[3]);
+                        const unsigned ex = tot - a[3] + (unsigned)carry[m];
+                        carry[m] = (int)((unsigned)__builtin_amdgcn_readlane((int)tot, 63) + (unsigned)carry[m]);
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (i0 + (uint32_t)j >= (uint32_t)m) v[q][j] = (int)(a[j] + ex);
+                    }
                 }
             }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t i = base4 + 256u * (uint32_t)q + 4u * (uint32_t)lane + (uint32_t)j;
+                    if (i < n) r[i] = v[q][j];
+                }
         }
         return;
     }
@@ -328,63 +355,142 @@ __global__ __launch_bounds__(64) void ll_predict_kernel(LlParArgs A) {
     }
 
     // reconstruct_lpc_int
-    const int order = c.n_coeffs;
     if (!has_res) {   // no residual bytes: every residual, hence every sample, is 0
         for (uint32_t i = lane; i < n; i += 64) r[i] = 0;
         return;
     }
-    if (n <= (uint32_t)order) return;
-    const uint32_t sh = c.shift_bits & 63u;
-    cs[lane] = lane < order ? ldexp((double)c.coeffs[lane], -(int)sh) : 0.0;
-    __syncthreads();
-    double C[64];   // C[t][lane] = tap (lane - t - 1) mod 64: what sample t of a block adds to the prediction of sample `lane`
-#pragma unroll
-    for (int t = 0; t < 64; t++) C[t] = cs[(lane - t - 1) & 63];
+    // (n <= order: the residuals are the samples; everything longer is predict_rows' business)
+}
 
-    // The first `order` samples are the residuals themselves. The loop below predicts them like any other sample
-    // (from the samples before them), so their residuals get that prediction taken off beforehand.
+// Four LPC wrappers per wavefront, one per row of sixteen lanes - the same transposed recurrence, but a finished sample
+// reaches the row's other accumulators inside the multiply-add itself: v_fmac_f64 takes its first operand through DPP
+// (row_newbcast:t = lane t of every row), so a step is v_floor_f64 + v_fmac_f64_dpp, no v_readlane and no scalar
+// registers in the loop (the 64-lane form spends floor + 2 readlane + fma on ONE wrapper's step). A row's sixteen
+// accumulators cover taps up to 16 - Q, where Q is how many lanes are collected and re-armed together (a lane's
+// accumulator is final after its own step and receives the next block's first contribution 16 - order steps later):
+// Q = 8 for orders <= 8, Q = 4 for orders <= 12 (the format's maximum). Residuals are fetched a super-block of
+// 16 x 16 samples ahead, so no step waits for memory.
+template <int Q>
+__device__ __forceinline__ void predict_rows(const LlParArgs &A, const unsigned chi, const int lane, double *cs, const bool act) {
+    // (a row without an LPC wrapper of its own - `act` false - runs along on zeros and touches no memory)
+    const int rl = lane & 15, row0 = lane & 48;
+    const LlChannelDev *cd = A.ch + (act ? chi : 0u);
+    int *r = A.scratch + cd->out_off;
+    const uint32_t n = act ? cd->samples : 0u;
+    const int order = act ? (int)cd->n_coeffs : 0;
+    const uint32_t sh = cd->shift_bits & 63u;
+    wave_sync_l();
+    cs[lane] = rl < order ? ldexp((double)cd->coeffs[rl], -(int)sh) : 0.0;
+    wave_sync_l();
+    double C[16];   // C[t][lane] = tap (rl - t - 1) mod 16 of the row's wrapper
+#pragma unroll
+    for (int t = 0; t < 16; t++) C[t] = cs[row0 + ((rl - t - 1) & 15)];
     double acc;
     {
-        long long v = (uint32_t)lane < n ? (long long)r[lane] : 0;
-        if (lane < order) {
+        long long v = (uint32_t)rl < n ? (long long)r[rl] : 0;
+        if (rl < order) {   // the first `order` samples are their residuals: take the loop's prediction off beforehand
             long long pred = 0;
-            for (int j = 0; j < lane; j++) pred += (long long)c.coeffs[j] * (long long)r[lane - 1 - j];
+            for (int j = 0; j < rl; j++) pred += (long long)cd->coeffs[j] * (long long)r[rl - 1 - j];
             v -= pred >> sh;
         }
         acc = (double)v;
     }
-    double outv = 0.0;
-    bool bad = false;
-    const uint32_t nb = (n + 63u) >> 6;
-    for (uint32_t b = 0; b < nb; b++) {
-        const uint32_t nxt = 64u * (b + 1u) + (uint32_t)lane;
-        const double rn = nxt < n ? (double)r[nxt] : 0.0;
+    // wave-uniform block count: the longest of the four wrappers (a shorter one runs on over zero residuals, unstored)
+    uint32_t nmax = n;
 #pragma unroll
-        for (int t = 0; t < 64; t++) {
-            const double x = floor(acc);
-            const int lo = __builtin_amdgcn_readlane(__double2loint(x), t);
-            const int hi = __builtin_amdgcn_readlane(__double2hiint(x), t);
-            acc = fma(C[t], __hiloint2double(hi, lo), acc);
-            // a lane's accumulator is final after its own step and takes nothing more before step lane + 52, so the
-            // finished half of the block is collected, and re-armed with the next block's residuals, 32 lanes at a time
-            if (t == 31 && lane < 32) {
-                outv = acc;
-                acc = rn;
-            }
-            if (t == 63 && lane >= 32) {
-                outv = acc;
-                acc = rn;
+    for (int k = 1; k < 4; k++) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)n, 16 * k);
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+        nmax = o > f ? o : f;
+    }
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    const uint32_t nb = (nmax + 15u) >> 4;
+    // Memory is touched at ONE point per super-block of kSb blocks: wait for what was issued a super-block ago (the
+    // residuals of this one, the samples of the one before - both long complete), then issue the next residual loads
+    // and the finished samples' stores, then run kSb x 16 steps on registers. (Loads and stores inside the stepping
+    // loop made the compiler wait for all outstanding memory operations at every block: the loop-carried count is
+    // unknown to it, and a block then cost a memory round trip.)
+    constexpr int kSb = 16;
+    auto fetch = [&](int (&buf)[kSb], const uint32_t b0) {
+#pragma unroll
+        for (int j = 0; j < kSb; j++) {
+            const uint32_t i = 16u * (b0 + (uint32_t)j) + (uint32_t)rl;
+            buf[j] = i < n ? r[i] : 0;
+        }
+    };
+    int pf[kSb], outs[kSb];
+    fetch(pf, 1u);
+#pragma unroll
+    for (int j = 0; j < kSb; j++) outs[j] = 0;
+    double outv = 0.0, worst = 0.0;
+    for (uint32_t sb = 0; (uint32_t)kSb * sb < nb + (uint32_t)kSb; sb++) {   // (one extra round stores the last super-block)
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        int cur[kSb];
+#pragma unroll
+        for (int j = 0; j < kSb; j++) cur[j] = pf[j];
+        fetch(pf, (uint32_t)kSb * (sb + 1u) + 1u);
+        if (sb > 0) {
+#pragma unroll
+            for (int j = 0; j < kSb; j++) {
+                const uint32_t i = 16u * ((uint32_t)kSb * (sb - 1u) + (uint32_t)j) + (uint32_t)rl;
+                if (i < n) r[i] = outs[j];
             }
         }
-        const double s = floor(outv);
-        const uint32_t i = 64u * b + (uint32_t)lane;
-        if (i < n) {
-            const bool in_range = fabs(s) < 2147483648.0;   // (false for NaN too)
-            if (!in_range) bad = true;
-            r[i] = in_range ? (int)s : 0;   // a flagged wrapper is decoded again by the serial kernel
+        if ((uint32_t)kSb * sb >= nb) break;
+#pragma unroll
+        for (int j = 0; j < kSb; j++) {
+            const double rn = (double)cur[j];
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                double x;
+                // (two wait states between a VALU write and a DPP read of the same register)
+                asm("v_floor_f64 %1, %0\n\ts_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                    : "+v"(acc), "=&v"(x)
+                    : "v"(C[t]), "n"(t));
+                if (t % Q == Q - 1) {
+                    const bool mine = rl / Q == t / Q;
+                    outv = mine ? acc : outv;
+                    acc = mine ? rn : acc;
+                }
+            }
+            // The largest magnitude is checked once, behind the loop (v_cvt saturates meanwhile; a wrapper that leaves the
+            // i32 range is decoded again by the serial kernel, so what is stored for it does not matter). Lanes behind a
+            // shorter wrapper's end run on over zero residuals and are counted too: at worst a needless serial decode.
+            const double sv = floor(outv);
+            worst = fmax(worst, fabs(sv));   // (a NaN can only follow a finite value beyond the range, which is recorded)
+            outs[j] = (int)sv;
         }
     }
+    const bool bad = !(worst < 2147483648.0);
     if (bad) A.serial[chi] = 1;
+}
+
+// Does wrapper `chi` take the row form? (LPC with residuals, more samples than taps, not handed to the serial kernel)
+__device__ __forceinline__ bool takes_rows(const LlParArgs &A, const unsigned chi, int &order) {
+    order = 0;
+    if (chi >= A.n_ch || A.serial[chi]) return false;
+    const LlChannelDev *cd = A.ch + chi;
+    order = cd->n_coeffs;
+    return order > 0 && order <= 12 && cd->len > 0 && cd->samples > (uint32_t)order;
+}
+
+// Workgroups [0, ceil(n_ch / 4)): the LPC wrappers, four per wavefront; workgroups behind them: one per wrapper for
+// everything else (fixed predictors, raw, silent), so a frame's fixed-predictor channel never waits behind a recurrence.
+__global__ __launch_bounds__(64) void ll_predict_kernel(LlParArgs A) {
+    __shared__ double cs[64];
+    const int lane = (int)threadIdx.x;
+    const unsigned groups = (A.n_ch + 3u) / 4u;
+    int order;
+    if (blockIdx.x < groups) {
+        const unsigned chi = 4u * blockIdx.x + ((unsigned)lane >> 4);
+        const bool rows = takes_rows(A, chi, order);
+        if (__ballot(rows) == 0ull) return;
+        if (__ballot(rows && order > 8) == 0ull) predict_rows<8>(A, chi, lane, cs, rows);
+        else predict_rows<4>(A, chi, lane, cs, rows);
+        return;
+    }
+    const unsigned chi = blockIdx.x - groups;   // (uniform)
+    if (!takes_rows(A, chi, order)) predict_one(A, chi, lane, cs);
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
@@ -395,7 +501,7 @@ int launch_ll_decode_parallel(const LlParArgs &A, unsigned max_tiles, hipStream_
         hipLaunchKernelGGL(ll_rice_chain_kernel, dim3(A.n_ch), dim3(64), 0, s, A);
         hipLaunchKernelGGL(ll_rice_decode_kernel, dim3(A.n_ch, (max_tiles + 63) / 64), dim3(64), 0, s, A);
     }
-    hipLaunchKernelGGL(ll_predict_kernel, dim3(A.n_ch), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(ll_predict_kernel, dim3((A.n_ch + 3u) / 4u + A.n_ch), dim3(64), 0, s, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     return 0;
