@@ -45,7 +45,7 @@ struct LlDecArgs {
 // Parallel form of the ALPC decode (lldec_kernels.hip). A Rice stream is cut into tiles of kRiceTileBits bits;
 // `tile0` is the running tile count over the wrappers (0 tiles for raw / silent wrappers and for those the host
 // already handed to the serial kernel through `serial`).
-constexpr int kRiceTileBits = 2048;
+constexpr int kRiceTileBits = 1024;
 constexpr int kRiceStates = 16;       // entry states of a tile: skip 0..k bits (k <= 14), or "inside a unary run" (k + 1)
 constexpr int kRiceMaxK = kRiceStates - 2;
 struct LlParArgs {

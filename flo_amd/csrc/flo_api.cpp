@@ -1432,8 +1432,8 @@ static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes,
         long long csum = 0;
         for (unsigned q = 0; q < d.n_coeffs; q++) csum += d.coeffs[q] < 0 ? -(long long)d.coeffs[q] : (long long)d.coeffs[q];
         if (force_serial || (rice && d.rice_k > kRiceMaxK) || csum >= (1ll << 21) || (d.n_coeffs && (d.shift_bits & 63u) > 20u)) serial[i] = 1;
-        if (rice && d.len > 64u * 1024u * 1024u) serial[i] = 1;   // the tile stages put a wrapper's tiles in gridDim.y (<= 65535)
-        const unsigned nt = rice && !serial[i] ? (d.len + 255u) / 256u : 0u;
+        if (rice && d.len > 16u * 1024u * (unsigned)kRiceTileBits) serial[i] = 1;   // the tile stages put a wrapper's tiles (four per workgroup at least) in gridDim.y (<= 65535)
+        const unsigned nt = rice && !serial[i] ? (d.len + (unsigned)kRiceTileBits / 8u - 1u) / ((unsigned)kRiceTileBits / 8u) : 0u;
         tile0[i + 1] = tile0[i] + nt;
         if (nt > max_tiles) max_tiles = nt;
     }

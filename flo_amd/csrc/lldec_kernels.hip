@@ -40,7 +40,9 @@ __device__ __forceinline__ void wave_sync_l() {
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
 }
-constexpr int kTileWords = kRiceTileBits / 32;   // 64
+constexpr int kTileWords = kRiceTileBits / 32;
+constexpr int kTileWordsLog2 = kTileWords == 64 ? 6 : kTileWords == 32 ? 5 : 4;
+static_assert((1 << kTileWordsLog2) == kTileWords, "tile of 512, 1024 or 2048 bits");
 constexpr int kScanTiles = 4;                    // tiles per wavefront in rice_scan at k = 14 (16 entry states); 64 / (k + 2) in general
 constexpr int kScanTilesMax = 32;                // ... at k = 0
 constexpr int kScanStride = kTileWords + 2;      // a window read touches word w + 1
@@ -103,52 +105,106 @@ __device__ __forceinline__ bool is_rice(const LlChannelDev &c) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ 1. tile tables
-__global__ __launch_bounds__(64) void ll_rice_scan_kernel(LlParArgs A) {
-    __shared__ uint32_t words[kScanTilesMax * kScanStride];
+// Walking a tile from every one of its k + 2 entry states repeats itself: the parses fall into step with each other
+// after a few codes (two that reach the same bit position are one parse from there on). So the walk has two phases:
+//   phase 1: k + 2 lanes per tile, as many tiles as fit a wavefront, eight wavefronts per workgroup - every entry state
+//            is walked up to the first position at or behind bit kScanFrontier;
+//   phase 2: of the lanes of a tile that stopped at the same position one (the lowest) is its leader; the leaders of
+//            the whole workgroup - one or two per tile - are packed into as few wavefronts as they need and walk the
+//            rest of their tiles; a lane's result is its own count up to the frontier plus its leader's behind it.
+// (All k + 2 lanes to the end of the tile was 975 vector instructions per tile, the kernel at the issue limit.)
+constexpr int kScanWaves = 8;
+#ifndef FLO_SCAN_FRONTIER
+#define FLO_SCAN_FRONTIER 192
+#endif
+constexpr uint32_t kScanFrontier = FLO_SCAN_FRONTIER;   // (>= the tile: one phase)
+
+__global__ __launch_bounds__(64 * kScanWaves) void ll_rice_scan_kernel(LlParArgs A) {
+    __shared__ uint32_t words[kScanWaves * kScanTilesMax * kScanStride];
+    __shared__ uint32_t posv[64 * kScanWaves], slotv[64 * kScanWaves], list[64 * kScanWaves], res[64 * kScanWaves];
+    __shared__ uint32_t count;
     const unsigned ch = blockIdx.x;
     const unsigned nt = A.tile0[ch + 1] - A.tile0[ch];
     const LlChannelDev c = A.ch[ch];
     const uint32_t k = c.rice_k;
-    // k + 2 lanes per tile (one per entry state), as many tiles as fit the wavefront. The grid is sized for four tiles
-    // per wavefront (k = 14): with a smaller k the surplus workgroups find nothing to do.
+    // The grid is sized for four tiles per wavefront (k = 14): with a smaller k the surplus workgroups find nothing to do.
     const uint32_t S = k + 2u, tpw = 64u / S;
-    const unsigned t0 = blockIdx.y * tpw;
-    if (t0 >= nt) return;
-    const int lane = (int)threadIdx.x;
+    const unsigned t0g = blockIdx.y * (kScanWaves * tpw);
+    if (t0g >= nt) return;   // (the whole workgroup)
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) count = 0;
+    const unsigned t0 = t0g + (unsigned)wave * tpw;
     const uint8_t *p = A.bytes + c.off;
-    // the tiles are consecutive words of the stream: word i of the wave goes to tile i / 64 (the two spare words of a
-    // tile's row repeat the next tile's first two)
-    stage_words(p, c.len, t0 * kTileWords, (int)(tpw * kTileWords + 2), lane, [&](int i, uint32_t v) {
-        const int tile = i >> 6, w = i & 63;
-        if (tile < (int)tpw) words[tile * kScanStride + w] = v;
-        if (w < 2 && tile > 0) words[(tile - 1) * kScanStride + kTileWords + w] = v;
-    });
+    uint32_t *wrows = words + wave * kScanTilesMax * kScanStride;
+    // a wavefront's tiles are consecutive words of the stream: word i goes to tile i / kTileWords (the two spare words
+    // of a tile's row repeat the next tile's first two)
+    if (t0 < nt)
+        stage_words(p, c.len, t0 * kTileWords, (int)(tpw * kTileWords + 2), lane, [&](int i, uint32_t v) {
+            const int tile = i >> kTileWordsLog2, w = i & (kTileWords - 1);
+            if (tile < (int)tpw) wrows[tile * kScanStride + w] = v;
+            if (w < 2 && tile > 0) wrows[(tile - 1) * kScanStride + kTileWords + w] = v;
+        });
     __syncthreads();
-    const uint32_t tile = (uint32_t)lane / S, st = (uint32_t)lane - tile * S;
-    if (tile >= tpw || t0 + tile >= nt) return;
-    const uint32_t *w = words + tile * kScanStride;
-    // One loop iteration per lane = one look at the 32 bits at `pos`, where the terminator of the current code (already
-    // counted) is being searched: either the window is all ones (32 bits further, still inside the run) or it shows
-    // the terminating 0, behind which k remainder bits are skipped and - if that is still inside the tile - the next
-    // code starts. Straight-line, predicated by `active`: nested data-dependent loops cost more in exec-mask
+    // One step = one look at the 32 bits at `pos`, where the terminator of the current code (already counted) is being
+    // searched: either the window is all ones (32 bits further, still inside the run) or it shows the terminating 0,
+    // behind which k remainder bits are skipped and - if that is still inside the tile - the next code starts.
+    // A lane that has left its tile keeps the way it left in `pos` itself: T + (0..k remainder bits still to skip in the
+    // next tile), or T + k + 1 when it left inside a run - its exit state is pos - T (and what it reads there are the
+    // row's two spare words). Straight-line, predicated by `go`: nested data-dependent loops cost more in exec-mask
     // bookkeeping than in arithmetic.
-    uint32_t pos = st <= k ? st : 0u, n = st <= k ? 1u : 0u, exit_state = k + 1u;
-    bool active = true;
-    while (__ballot(active) != 0ull) {
-        const uint32_t rp = active ? pos : 0u;
-        const uint32_t ones = leading_ones(window32(w, rp));
-        const uint32_t z = rp + ones;                       // the terminating 0, or 32 bits on
-        const bool term = ones < 32u && z < (uint32_t)kRiceTileBits;
-        const uint32_t nxt = term ? z + 1u + k : z;
-        const bool leaves = nxt >= (uint32_t)kRiceTileBits;
-        // leaving behind a terminator: 0..k bits into the next tile; leaving inside a run: the run goes on there
-        const bool out = active && leaves;
-        exit_state = out ? (term ? nxt - (uint32_t)kRiceTileBits : k + 1u) : exit_state;
-        n += (active && !leaves && term) ? 1u : 0u;
-        pos = active ? nxt : pos;
-        active = active && !leaves;
+    constexpr uint32_t T = (uint32_t)kRiceTileBits;
+    const uint32_t kp1 = k + 1u;
+    auto step = [&](const uint32_t *w, const bool go, uint32_t &pos, uint32_t &n) {
+        // (the two words arrive as one 64-bit register pair, high word first: ds_read2_b32 with its offsets crossed)
+        unsigned long long two;
+        asm volatile("ds_read2_b32 %0, %1 offset0:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(two) : "v"((uint32_t)(uintptr_t)(w + (pos >> 5))) : "memory");
+        const uint32_t ones = leading_ones((uint32_t)((two << (pos & 31u)) >> 32));
+        const uint32_t z = pos + ones;                      // the terminating 0, or 32 bits on
+        const bool in_tile = z < T;
+        const bool term = in_tile && ones < 32u;
+        const uint32_t npos = (in_tile ? z : T + kp1) + (term ? kp1 : 0u);
+        n += (go && term && npos < T) ? 1u : 0u;
+        pos = go ? npos : pos;
+    };
+    const uint32_t tile = (uint32_t)lane / S, st = (uint32_t)lane - tile * S;
+    const bool mine = tile < tpw && t0 + tile < nt;
+    const uint32_t row = (uint32_t)wave * kScanTilesMax + (mine ? tile : 0u);
+    uint32_t pos = mine ? (st <= k ? st : 0u) : T + kp1, n = st <= k ? 1u : 0u;
+    while (__ballot(pos < kScanFrontier) != 0ull) step(words + row * kScanStride, pos < kScanFrontier, pos, n);
+    // leaders: the lowest lane of the tile that stopped at this position
+    const bool cand = pos < T;
+    const uint32_t g0 = (uint32_t)wave * 64u + tile * S;
+    uint32_t leader = st;
+    if (kScanFrontier < T) {
+        posv[tid] = pos;
+        wave_sync_l();
+        for (uint32_t j = 0; j + 1u < S; j++)   // (uniform bound)
+            if (cand && j < st && leader == st && posv[g0 + j] == pos) leader = j;
+        if (cand && leader == st) {
+            const uint32_t slot = atomicAdd(&count, 1u);
+            list[slot] = (row << 16) | pos;
+            slotv[tid] = slot;
+        }
+        __syncthreads();
+        const uint32_t cnt = count;
+        const bool have = (uint32_t)tid < cnt;
+        if (__ballot(have) != 0ull) {   // (whole wavefronts without work skip)
+            const uint32_t e = have ? list[tid] : 0u;
+            const uint32_t *w2 = words + (e >> 16) * kScanStride;
+            uint32_t pos2 = have ? e & 0xFFFFu : T + kp1, n2 = 0;
+            while (__ballot(pos2 < T) != 0ull) step(w2, pos2 < T, pos2, n2);
+            if (have) res[tid] = (pos2 - T) | (n2 << 5);
+        }
+        __syncthreads();
     }
-    A.tabs[(size_t)(A.tile0[ch] + t0 + tile) * kRiceStates + st] = exit_state | (n << 5);
+    if (mine) {
+        uint32_t o = (pos - T) | (n << 5);
+        if (cand) {
+            const uint32_t r = res[slotv[g0 + leader]];
+            o = (r & 31u) | ((n + (r >> 5)) << 5);
+        }
+        A.tabs[(size_t)(A.tile0[ch] + t0 + tile) * kRiceStates + st] = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ 2. the chain
@@ -196,8 +252,9 @@ __global__ __launch_bounds__(64) void ll_rice_chain_kernel(LlParArgs A) {
 // ------------------------------------------------------------------------------------------------ 3. residuals
 __global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
     // 64 tiles of 64 words; one pad word per tile so that lanes at the same offset of their tiles hit 64 banks
-    __shared__ uint32_t words[64 * (kTileWords + 1) + kDecOver + 4];
-    __shared__ uint32_t stg[64 * 17], s_cnt[64], s_base[64];   // 16 pending values per lane (one pad word per row), their count and place
+    __shared__ uint32_t words[64 * (kTileWords + 1) + kDecOver + kDecOver / kTileWords + 4];
+    __shared__ uint32_t stg[64 * 17];   // 16 pending values per lane (one pad word per row),
+    __shared__ uint2 s_cb[64];          // their count and place
     const unsigned ch = blockIdx.x;
     const unsigned first = A.tile0[ch], nt = A.tile0[ch + 1] - first;
     const unsigned t0 = blockIdx.y * 64u;
@@ -205,7 +262,7 @@ __global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
     const int lane = (int)threadIdx.x;
     const LlChannelDev c = A.ch[ch];
     const uint8_t *p = A.bytes + c.off;
-    stage_words(p, c.len, t0 * kTileWords, 64 * kTileWords + kDecOver, lane, [&](int i, uint32_t v) { words[i + (i >> 6)] = v; });
+    stage_words(p, c.len, t0 * kTileWords, 64 * kTileWords + kDecOver, lane, [&](int i, uint32_t v) { words[i + (i >> kTileWordsLog2)] = v; });
     __syncthreads();
     const unsigned t = t0 + lane;
     const bool have_tile = t < nt;   // (lanes without a tile stay for the cooperative stores)
@@ -213,10 +270,14 @@ __global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
     const uint32_t k = c.rice_k, n = c.samples;
     int *out = A.scratch + c.out_off;
     // bit positions are relative to the wavefront's first tile; word i lives at words[i + i / 64]
-    auto win = [&](uint32_t pos) -> uint32_t {
-        const uint32_t i = pos >> 5, sh = pos & 31u;
-        const unsigned long long two = ((unsigned long long)words[i + (i >> 6)] << 32) | words[i + 1 + ((i + 1) >> 6)];
-        return (uint32_t)((two << sh) >> 32);
+    // the 64 bits at `pos` (three words, one LDS round trip): a code's unary part is looked at 32 bits at a time, and
+    // its k <= 14 remainder bits lie inside the same 64 whenever the terminator does (a second, dependent window read
+    // for them was a third of an iteration's latency)
+    auto win64 = [&](uint32_t pos, uint32_t &hi, uint32_t &lo) {
+        const uint32_t i = pos >> 5, sh = pos & 31u, i1 = i + 1u, i2 = i + 2u;
+        const uint32_t w0 = words[i + (i >> kTileWordsLog2)], w1 = words[i1 + (i1 >> kTileWordsLog2)], w2 = words[i2 + (i2 >> kTileWordsLog2)];
+        hi = (uint32_t)(((((unsigned long long)w0) << 32 | w1) << sh) >> 32);
+        lo = (uint32_t)(((((unsigned long long)w1) << 32 | w2) << sh) >> 32);
     };
     const uint32_t tile_lo = (uint32_t)lane * kRiceTileBits, tile_hi = tile_lo + kRiceTileBits;
     const uint32_t limit = 64u * kRiceTileBits + 32u * (kDecOver - 2);   // staged bits a run may be followed through
@@ -232,28 +293,37 @@ __global__ __launch_bounds__(64) void ll_rice_decode_kernel(LlParArgs A) {
     // = up to 16 consecutive values of one lane.
     uint32_t pend = 0, pbase = idx, it = 0;
     auto flush = [&]() {
-        s_cnt[lane] = pend;
-        s_base[lane] = pbase;
+        s_cb[lane] = make_uint2(pend, pbase);
         wave_sync_l();
+        // (all the reads first: one LDS round trip for the sixteen rows instead of one per row)
+        uint2 cb[16];
+        uint32_t val[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const int row = 4 * j + (lane >> 4), col = lane & 15;
-            if ((uint32_t)col < s_cnt[row]) out[s_base[row] + (uint32_t)col] = (int)stg[row * 17 + col];
+            cb[j] = s_cb[row];
+            val[j] = stg[row * 17 + col];
         }
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if ((uint32_t)(lane & 15) < cb[j].x) out[cb[j].y + (uint32_t)(lane & 15)] = (int)val[j];
         wave_sync_l();
         pend = 0;
         pbase = idx;
     };
     while (__ballot(active) != 0ull) {
         const uint32_t rp = active ? pos : tile_lo;
-        const uint32_t ones = leading_ones(win(rp));
+        uint32_t whi, wlo;
+        win64(rp, whi, wlo);
+        const uint32_t ones = leading_ones(whi);
         const uint32_t z = rp + ones, q2 = q + ones;
         const bool term = ones < 32u;
         // our own code: the 256-ones escape (rice.rs:134-139), or a run past what is staged -> the serial reader
         const bool esc = !skip && (q2 >= 256u || z >= limit);
         // an inherited run must end inside the tile
         const bool lost = skip && (z >= tile_hi);
-        const uint32_t rem = k ? win((active && term && !esc) ? z + 1u : tile_lo) >> (32u - k) : 0u;
+        // the 32 bits behind the terminator: ({whi, wlo} << (ones + 1)) >> 32 (v_alignbit; ones <= 31 when it matters)
+        const uint32_t rem = (uint32_t)((unsigned long long)__builtin_amdgcn_alignbit(whi, wlo, (31u - ones) & 31u) >> (32u - k));   // (k = 0: nothing)
         const bool emit = active && term && !skip && !esc;
         if (emit) {
             const uint32_t u = (q2 << k) | rem;
@@ -497,7 +567,7 @@ __global__ __launch_bounds__(64) void ll_predict_kernel(LlParArgs A) {
 int launch_ll_decode_parallel(const LlParArgs &A, unsigned max_tiles, hipStream_t s) {
     if (!A.n_ch) return 0;
     if (max_tiles) {
-        hipLaunchKernelGGL(ll_rice_scan_kernel, dim3(A.n_ch, (max_tiles + kScanTiles - 1) / kScanTiles), dim3(64), 0, s, A);
+        hipLaunchKernelGGL(ll_rice_scan_kernel, dim3(A.n_ch, (max_tiles + kScanWaves * kScanTiles - 1) / (kScanWaves * kScanTiles)), dim3(64 * kScanWaves), 0, s, A);
         hipLaunchKernelGGL(ll_rice_chain_kernel, dim3(A.n_ch), dim3(64), 0, s, A);
         hipLaunchKernelGGL(ll_rice_decode_kernel, dim3(A.n_ch, (max_tiles + 63) / 64), dim3(64), 0, s, A);
     }
