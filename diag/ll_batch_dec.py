@@ -16,6 +16,10 @@ t = time.perf_counter()
 for _ in range(3): bl.decode_to(dst.data_ptr(), n)
 d = (time.perf_counter() - t) / 3
 print(f"decode {d*1e3:.3f} ms  {n/d/1e9:.1f} Gsamples/s")
+ctx.profile_enable(True); ctx.profile_reset()
+for _ in range(3): bl.decode_to(dst.data_ptr(), n)
+print("event-timed per call:", {k: round(ctx.profile_query(k)[0] / 3, 3) for k in ("ll_decode_parallel", "ll_decode", "ll_finish")})
+ctx.profile_enable(False)
 # exactness: the decoded floats are the 16-bit quantisation of the input
 src = bl.download_pcm(0)
 import numpy as np

@@ -1415,10 +1415,10 @@ struct LlWork {
 static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes, int nch, float *d_out, int *d_out_i32) {
     const size_t n_out = (size_t)w.out_sf * (size_t)nch;
     if (!n_out) return FLO_OK;
-    DevMem d_ch, d_fr, d_scr, d_t0, d_ser, d_tabs, d_ent;
-    QuiesceOnExit quiesce_d_ch(c);
+    const auto t_enter = std::chrono::steady_clock::now();
+    DevMem d_desc, d_scr, d_tabs, d_ent;
+    QuiesceOnExit quiesce_d_desc(c);
     int rc;
-    if ((rc = upload(c, d_ch, w.chs)) || (rc = upload(c, d_fr, w.frs))) return rc;
     // Rice tiles per wrapper; wrappers the parallel form does not take (rice.rs k > 14; coefficient sums or shifts
     // that would leave the exact range of the f64 recurrence: it holds r * 2^shift + sum c * s, |r|, |s| < 2^31, in
     // 53 bits) go to the serial kernel
@@ -1449,7 +1449,27 @@ static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes,
         fprintf(stderr, "[flo] ll decode: %zu wrappers: LPC order <= 8 %zu, order 9..12 %zu, fixed %zu, raw/silent/empty %zu, serial %zu\n", w.chs.size(), lpc8,
                 lpc, fixed, other, ser);
     }
-    if ((rc = upload(c, d_t0, tile0)) || (rc = upload(c, d_ser, serial))) return rc;
+    // the four descriptor arrays go up as ONE copy out of pinned memory, queued in front of the kernels (four copies out
+    // of pageable vectors each held the host until the driver had staged them: 0.15 ms of an idle device per call)
+    auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_ch = 0, o_fr = up256(w.chs.size() * sizeof(LlChannelDev)), o_t0 = o_fr + up256(w.frs.size() * sizeof(LlFrameDev)),
+                 o_ser = o_t0 + up256(tile0.size() * sizeof(unsigned int)), desc_bytes = o_ser + up256(serial.size() * sizeof(int));
+    if ((rc = ctx_stager(c)) != FLO_OK) return rc;
+    {
+        std::string perr;
+        uint8_t *pin = (uint8_t *)stager_pinned(c->stager, desc_bytes, perr);
+        if (!pin) return fail(c, FLO_ERR_NOMEM, perr);
+        memcpy(pin + o_ch, w.chs.data(), w.chs.size() * sizeof(LlChannelDev));
+        memcpy(pin + o_fr, w.frs.data(), w.frs.size() * sizeof(LlFrameDev));
+        memcpy(pin + o_t0, tile0.data(), tile0.size() * sizeof(unsigned int));
+        memcpy(pin + o_ser, serial.data(), serial.size() * sizeof(int));
+        HIPCHK(c, pool_alloc(&d_desc.p, desc_bytes));
+        HIPCHK(c, hipMemcpyAsync(d_desc.p, pin, desc_bytes, hipMemcpyHostToDevice, c->stream));   // (read before this function's final synchronise)
+    }
+    LlChannelDev *const d_ch = reinterpret_cast<LlChannelDev *>(d_desc.as<uint8_t>() + o_ch);
+    LlFrameDev *const d_fr = reinterpret_cast<LlFrameDev *>(d_desc.as<uint8_t>() + o_fr);
+    unsigned int *const d_t0 = reinterpret_cast<unsigned int *>(d_desc.as<uint8_t>() + o_t0);
+    int *const d_ser = reinterpret_cast<int *>(d_desc.as<uint8_t>() + o_ser);
     const size_t tiles = tile0.back();
     hipError_t e = pool_alloc(&d_scr.p, w.scratch ? w.scratch * sizeof(int) : 16);
     if (e == hipSuccess) e = pool_alloc(&d_tabs.p, tiles ? tiles * kRiceStates * sizeof(unsigned int) : 16);
@@ -1462,16 +1482,18 @@ static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes,
     if (e == hipSuccess && d_out && partial) e = hipMemsetAsync(d_out, 0, n_out * sizeof(float), c->stream);
     if (e == hipSuccess && d_out_i32 && partial) e = hipMemsetAsync(d_out_i32, 0, n_out * sizeof(int), c->stream);
     if (e != hipSuccess) return fail(c, FLO_ERR_NOMEM, std::string("decode buffers: ") + hipGetErrorString(e));
-    LlParArgs P{d_bytes, d_ch.as<LlChannelDev>(), (unsigned)w.chs.size(), d_scr.as<int>(),
-                d_t0.as<unsigned int>(), d_tabs.as<unsigned int>(), d_ent.as<uint2>(), d_ser.as<int>()};
+    LlParArgs P{d_bytes, d_ch, (unsigned)w.chs.size(), d_scr.as<int>(), d_t0, d_tabs.as<unsigned int>(), d_ent.as<uint2>(), d_ser};
     rc = timed_launch(c, "ll_decode_parallel", [&] { return launch_ll_decode_parallel(P, max_tiles, c->stream); });
     if (rc != FLO_OK) return rc;
-    LlDecArgs A{d_bytes, d_ch.as<LlChannelDev>(), (unsigned)w.chs.size(), d_scr.as<int>(), d_ser.as<int>()};
+    LlDecArgs A{d_bytes, d_ch, (unsigned)w.chs.size(), d_scr.as<int>(), d_ser};
     rc = timed_launch(c, "ll_decode", [&] { return launch_ll_decode(A, c->stream); });
     if (rc != FLO_OK) return rc;
-    LlFinishArgs F{d_fr.as<LlFrameDev>(), d_ch.as<LlChannelDev>(), (unsigned)w.frs.size(), nch, d_scr.as<int>(), d_out, d_out_i32};
+    LlFinishArgs F{d_fr, d_ch, (unsigned)w.frs.size(), nch, d_scr.as<int>(), d_out, d_out_i32};
     rc = timed_launch(c, "ll_finish", [&] { return launch_ll_finish(F, w.max_samples, c->stream); });
     if (rc != FLO_OK) return rc;
+    if (getenv("FLO_TRACE"))
+        fprintf(stderr, "[flo] ll decode: host time until the last launch %.0f us\n",
+                (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_enter).count() / 1e3);
     // the descriptor uploads read pageable vectors that die with this frame, and the temporaries go back to the pool
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FLO_OK;
@@ -1616,7 +1638,10 @@ static int batch_decode_lossless(flo_batch *b, float *dst, size_t dst_cap, uint6
     std::vector<LosslessWrapperInfo> wr;
     const uint8_t *base = nullptr;
     std::string err;
+    const bool trace = getenv("FLO_TRACE") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
     if (lossless_describe(b->ll, fr, wr, &base, err) != 0) return fail(c, FLO_ERR_STATE, err);
+    const auto t_1 = std::chrono::steady_clock::now();
     LlWork w;
     w.chs.reserve(wr.size());
     w.frs.reserve(fr.size());
@@ -1665,7 +1690,14 @@ static int batch_decode_lossless(flo_batch *b, float *dst, size_t dst_cap, uint6
     }
     const uint64_t total = w.out_sf * b->ch;
     if (total > dst_cap) return fail(c, FLO_ERR_ARG, "destination too small for the decoded batch");
-    return ll_decode_device(c, w, base, b->ch, dst, nullptr);
+    const auto t_2 = std::chrono::steady_clock::now();
+    const int rc = ll_decode_device(c, w, base, b->ch, dst, nullptr);
+    if (trace) {
+        const auto t_3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b2) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b2 - a).count() / 1e3; };
+        fprintf(stderr, "[flo] batch lossless decode: describe %.0f us, descriptors %.0f us, device %.0f us\n", us(t_0, t_1), us(t_1, t_2), us(t_2, t_3));
+    }
+    return rc;
 }
 
 // Decode every clip of an encoded batch from its device bitstreams (no host round trip of the payload).

@@ -1056,6 +1056,7 @@ struct LosslessPlan {
     // host results
     std::vector<LLFrameOut> h_fout;
     std::vector<uint64_t> h_clip_bytes, h_file_bytes;
+    LLChan *h_chans_pin = nullptr;   // pinned mirror of d_chans for lossless_describe (allocated on first use)
     hipStream_t stream = nullptr;
 };
 
@@ -1070,6 +1071,7 @@ void lossless_plan_destroy(LosslessPlan *p) {
                     p->d_cf0, p->d_fsize, p->d_fsamp, p->d_cfn, p->d_crc, p->d_part};
     for (void *q : ptrs)
         if (q) pool_free(q);
+    if (p->h_chans_pin) (void)hipHostFree(p->h_chans_pin);
     delete p;
 }
 
@@ -1292,9 +1294,15 @@ int lossless_describe(LosslessPlan *p, std::vector<LosslessFrameInfo> &frames, s
         err = "lossless_describe: the batch has not been collected";
         return -1;
     }
-    std::vector<LLChan> chans(p->n_chans);
+    // (into pinned memory: a pageable destination made this copy 0.1 ms of every batch decode)
+    if (p->n_chans && !p->h_chans_pin && hipHostMalloc((void **)&p->h_chans_pin, p->n_chans * sizeof(LLChan), hipHostMallocDefault) != hipSuccess) {
+        p->h_chans_pin = nullptr;
+        err = "lossless_describe: no pinned memory for the channel records";
+        return -1;
+    }
+    const LLChan *chans = p->h_chans_pin;
     if (p->n_chans) {
-        hipError_t e = hipMemcpy(chans.data(), p->d_chans, p->n_chans * sizeof(LLChan), hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpy(p->h_chans_pin, p->d_chans, p->n_chans * sizeof(LLChan), hipMemcpyDeviceToHost);
         if (e != hipSuccess) {
             err = hipGetErrorString(e);
             return -1;
