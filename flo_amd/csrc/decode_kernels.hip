@@ -59,18 +59,28 @@ __global__ __launch_bounds__(64, 3) void lossy_decode_kernel(LossyDecArgs D) {
     // the frame's bytes, staged whole (header, scale words, both channels' blobs: ~0.5 KB, 2.2 KB at most for what the
     // encoder makes); a frame that does not fit is parsed in global memory and only its blob comes here
     __shared__ __attribute__((aligned(16))) uint8_t sblob[kBlobStage + 16];
-    __shared__ unsigned long long s_foff[kDecRunLong + 1];
-    __shared__ uint32_t s_flen[kDecRunLong + 1];
+    __shared__ unsigned long long s_foff[kDecRunLong + 1], s_boff[kDecRunLong + 1];   // where a frame of the run lies, and the bytes of the channel being walked
+    __shared__ uint32_t s_blen[kDecRunLong + 1], s_flag[kDecRunLong + 1];
     // The workgroup is ONE wavefront: its LDS instructions execute in order, so the ordering points between the phases are
     // wave_sync() (a compiler fence), not __syncthreads() - whose s_waitcnt vmcnt(0) made every phase boundary wait for
     // the next frame's prefetch and for the previous block's output stores (several exposed HBM round trips per
     // channel-frame: most of what the kernel spent its time on).
     const int lane = (int)threadIdx.x;
-    const unsigned clip = blockIdx.x;   // clips in x: gridDim.y stops at 65535
-    if (clip >= (unsigned)D.n_clips) return;
+    // One wavefront = one CHANNEL of one run of one clip. The channels of a run write the same cache lines of the
+    // interleaved output (4 of every 4 x channels bytes each): their wavefronts must be on the same XCD - one L2 - and run
+    // side by side, so that a line is complete before it leaves the L2. Workgroups are dealt round-robin to the eight
+    // XCDs, so workgroups L and L + 8 are neighbours in time on one XCD: they are the two channels of one run. (One
+    // wavefront walking the run once per channel wrote every line twice, a run's length apart in time: half-filled
+    // lines went to memory twice - stereo decoded at 264 Gsamples/s where the same channel-frames as mono clips made 316.)
+    const unsigned nc = (unsigned)D.channels;
+    const unsigned L = blockIdx.x;
+    const uint32_t c = (L >> 3) % nc;
+    const unsigned long long P = (unsigned long long)(L / (8u * nc)) * 8u + (L & 7u);
+    if (P >= (unsigned long long)D.n_clips * D.n_runs) return;
+    const unsigned clip = (unsigned)(P % (unsigned)D.n_clips);   // (clips fastest)
     const unsigned nframes = D.clip_frames[clip];
     const unsigned run = (unsigned)D.run;
-    const unsigned h0 = blockIdx.y * run;              // first frame of the run = first output block
+    const unsigned h0 = (unsigned)(P / (unsigned)D.n_clips) * run;   // first frame of the run = first output block
     if (nframes < 2 || h0 + 1 >= nframes) return;
     const unsigned h1 = h0 + run < nframes - 1 ? h0 + run : nframes - 1;   // last frame of the run
     float *out = D.out + D.clip_out[clip];
@@ -101,84 +111,94 @@ __global__ __launch_bounds__(64, 3) void lossy_decode_kernel(LossyDecArgs D) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dst_last)::"memory");
 #endif
 
-    // where the run's frames are: one load per lane instead of one dependent load per frame
-    if ((unsigned)lane <= h1 - h0) {
-        const unsigned long long f = D.clip_frame0[clip] + h0 + (unsigned)lane;
-        s_foff[lane] = D.blob_off[f];
-        s_flen[lane] = D.blob_len[f];
-    }
-    wave_sync();
-    // A frame travels global memory -> registers -> LDS, and the registers are filled one frame ahead: the walk over a
-    // frame used to start with three dependent global round trips (offset, channel length, blob), which was most of
-    // what a wave spent its time on.
-    constexpr int kPre = (kBlobStage + 255) / 256;   // dwords per lane
-    uint32_t pre[kPre];
-    auto fetch = [&](unsigned h) {
-        const uint8_t *g = D.bytes + s_foff[h - h0];
-        const uint32_t len = s_flen[h - h0];
-        if (len > (uint32_t)kBlobStage) return;
-#pragma unroll
-        for (int j = 0; j < kPre; j++) {
-            if (256u * (uint32_t)j < len) {   // uniform: a frame is about 0.5 KB, two of the nine rows
-                const uint32_t i = 4u * ((uint32_t)lane + 64u * (uint32_t)j);
-                uint32_t w4 = 0;
-                if (i < len) __builtin_memcpy(&w4, g + i, 4);   // up to 3 bytes past the frame: inside the file + slack
-                pre[j] = w4;
+    // Where the run's frames are, and inside each frame where the sparse bytes of channel c are (deserialize_frame:
+    // [block_size][channels][25 x u16 per channel][per channel: u32 len, sparse bytes]): one lane per frame reads the few
+    // header bytes once per run and channel. The walk over the frames then stages nothing but the bytes of the channel
+    // it is decoding (a whole frame - both channels' bytes - was staged and its header walked again for every channel:
+    // a fifth of a channel-frame's time). False: a frame of the run is malformed.
+    auto index_run = [&](const uint32_t c) -> bool {
+        wave_sync();
+        if ((unsigned)lane <= h1 - h0) {
+            const unsigned long long f = D.clip_frame0[clip] + h0 + (unsigned)lane;
+            const unsigned long long foff = D.blob_off[f];
+            const uint32_t flen = D.blob_len[f];
+            const uint8_t *g = D.bytes + foff;
+            bool bad = flen < 2;
+            uint32_t nch = 0, pos = 0, blen = 0;
+            if (!bad) {
+                nch = g[1];
+                bad = g[0] != 0 /* only Long blocks are produced or accepted */ || nch > (uint32_t)D.channels;
+                pos = 2 + 50 * nch;
+                bad = bad || pos > flen;
             }
-        }
-    };
-    auto frame_ch = [&](const uint32_t c, const unsigned h, const uint8_t *data, const uint32_t len, auto IN_LDS) -> bool {
-        // (the lane index behind an optimisation barrier: inside the frame loop every lane-derived address is recomputed - a
-        // few integer operations - instead of being hoisted into dozens of loop-invariant registers)
-        const int ln = lane_id_opaque();
-        constexpr bool in_lds = decltype(IN_LDS)::value;
-        {
-            // deserialize_frame: [block_size][channels][25 x u16 per channel][per channel: u32 len, sparse bytes]
-            if (len < 2 || data[0] != 0 /* only Long blocks are produced or accepted */ || data[1] > D.channels) {
-                if (ln == 0) atomicExch(D.error, 1);
-                return false;
-            }
-            const uint32_t nch = data[1];
-            uint32_t pos = 2 + 50 * nch;
-            bool bad = pos > len;
-            uint32_t blen = 0;
-            for (uint32_t k = 0; k <= c && k < nch && !bad; k++) {   // walk to channel c's sparse blob
-                if (pos + 4 > len) {
+            for (uint32_t k = 0; k <= c && k < nch && !bad; k++) {   // walk to channel c's sparse bytes
+                if (pos + 4 > flen) {
                     bad = true;
                     break;
                 }
-                blen = rd_u32(data + pos);
+                blen = rd_u32(g + pos);
                 pos += 4;
-                if (pos + blen > len || pos + blen < pos) {
+                if (pos + blen > flen || pos + blen < pos) {
                     bad = true;
                     break;
                 }
                 if (k < c) pos += blen;
             }
-            if (bad) {
-                if (ln == 0) atomicExch(D.error, 1);
-                return false;
+            s_foff[lane] = foff;
+            s_boff[lane] = foff + pos;
+            s_blen[lane] = blen;
+            s_flag[lane] = bad ? 2u : (c < nch ? 1u : 0u);   // 1: the frame carries channel c (one with fewer channels leaves the others silent)
+        }
+        wave_sync();
+        bool any_bad = false;
+        for (unsigned i = 0; i <= h1 - h0; i++) any_bad = any_bad || s_flag[i] == 2u;   // (uniform)
+        if (any_bad && lane == 0) atomicExch(D.error, 1);
+        return !any_bad;
+    };
+    // A channel's bytes travel global memory -> registers -> LDS, and the registers are filled one frame ahead: the walk
+    // over a frame used to start with three dependent global round trips (offset, channel length, blob), which was most
+    // of what a wave spent its time on.
+    constexpr int kPre = (kBlobStage + 255) / 256;   // dwords per lane
+    uint32_t pre[kPre], pre_sfw = 0;
+    auto fetch = [&](const uint32_t c, const unsigned h) {
+        const uint32_t blen = s_blen[h - h0];
+        if (!s_flag[h - h0]) return;   // the frame does not carry this channel
+        if (lane < 25) {
+            const uint8_t *w = D.bytes + s_foff[h - h0] + 2u + 50u * c + 2u * (uint32_t)lane;
+            pre_sfw = (uint32_t)w[0] | ((uint32_t)w[1] << 8);
+        }
+        if (blen > (uint32_t)kBlobStage) return;
+        const uint8_t *g = D.bytes + s_boff[h - h0];
+#pragma unroll
+        for (int j = 0; j < kPre; j++) {
+            if (256u * (uint32_t)j < blen) {   // uniform: a channel's bytes are about 0.25 KB, one of the nine rows
+                const uint32_t i = 4u * ((uint32_t)lane + 64u * (uint32_t)j);
+                uint32_t w4 = 0;
+                if (i < blen) __builtin_memcpy(&w4, g + i, 4);   // up to 3 bytes past the blob: inside the file + slack
+                pre[j] = w4;
             }
-            const bool present = c < nch;      // a frame with fewer channels leaves the others silent
+        }
+    };
+    // one channel of one frame: `staged` - its sparse bytes are in sblob (from its first byte); else they are walked where
+    // they lie. `sfw`: the scale word of band `lane`.
+    auto frame_ch = [&](const uint32_t c, const unsigned h, const bool present, const uint32_t blen, const bool staged, const uint32_t sfw) -> bool {
+        // (the lane index behind an optimisation barrier: inside the frame loop every lane-derived address is recomputed - a
+        // few integer operations - instead of being hoisted into dozens of loop-invariant registers)
+        const int ln = lane_id_opaque();
+        {
             DSTAMP(1);
             if (present) {
                 // the record walk below is a chain of dependent byte reads: from LDS it costs a tenth of what it
                 // costs from global memory. Valid blobs are at most ~2.1 KB; anything longer is walked in place.
-                const uint8_t *sp = data + pos;
-                bool sp_lds = in_lds;
-                if (!in_lds && blen <= (uint32_t)kBlobStage) {
-                    for (uint32_t i = 4u * ln; i < blen; i += 256u) {
-                        uint32_t w4;
-                        __builtin_memcpy(&w4, sp + i, 4);   // up to 3 bytes past the blob: inside the file + slack
-                        *reinterpret_cast<uint32_t *>(sblob + i) = w4;
-                    }
-                    wave_sync();
-                    sp = sblob;
-                    sp_lds = true;
-                }
+                // Staged bytes are read through `sblob` itself: the compiler then knows they are in LDS (ds_read). Through
+                // a generic pointer every byte is a FLAT load, and the wait behind a flat load is s_waitcnt vmcnt(0)
+                // lgkmcnt(0) - it also waits for the next frame's prefetch and the previous block's output stores.
+                const uint8_t *sp = D.bytes + s_boff[h - h0];   // (generic: only the in-place walk reads through it)
+                const uint8_t *lsp = sblob;
+                const bool sp_lds = staged;
                 // scale factors: 2^((word - 32768) / 256), 0 when the word is 0 (decoder.rs:91-99)
                 if (ln < 25) {
-                    const uint32_t wv = rd_u16(data + 2 + 50 * c + 2 * ln);
+                    const uint32_t wv = sfw;
                     // kept as the reciprocal: one IEEE division per band here instead of sixteen per ln below (q / sf
                     // becomes q * (1 / sf): one rounding more, 6e-8 relative, far inside the 2e-6 the transform allows)
                     // (exp2f: the exponent is a multiple of 2^-8 in [-128, 128); one ulp from powf(2, .) at most, 1e-7 relative)
@@ -198,8 +218,8 @@ __global__ __launch_bounds__(64, 3) void lossy_decode_kernel(LossyDecArgs D) {
                 // the four bytes at blob position p0 (the blob is in LDS: two aligned dwords and a byte shift; up to seven bytes
                 // past p0 are touched, inside the staging buffer's slack)
                 auto bytes_at = [&](const uint32_t p0) -> uint32_t {
-                    const uint32_t a = (uint32_t)(uintptr_t)(sp + p0);
-                    const uint32_t *dw = reinterpret_cast<const uint32_t *>(sp + p0 - (a & 3u));
+                    const uint32_t a = (uint32_t)(uintptr_t)(lsp + p0);
+                    const uint32_t *dw = reinterpret_cast<const uint32_t *>(lsp + p0 - (a & 3u));
                     return __builtin_amdgcn_alignbyte(dw[1], dw[0], a & 3u);
                 };
                 // "a record starting at p0", from its first bytes w: the usual header is [zero run < 128][count] or [two-byte
@@ -225,13 +245,13 @@ __global__ __launch_bounds__(64, 3) void lossy_decode_kernel(LossyDecArgs D) {
                         p = p0, value = 0;
                         uint32_t shift = 0;
                         while (p < blen) {   // decode_varint (:170-188)
-                            const uint32_t b = sp[p++];
+                            const uint32_t b = lsp[p++];
                             value |= (b & 0x7Fu) << shift;
                             if (!(b & 0x80u)) break;
                             shift += 7;
                             if (shift >= 32) break;
                         }
-                        nz = p < blen ? (uint32_t)sp[p] : 0u;
+                        nz = p < blen ? (uint32_t)lsp[p] : 0u;
                     }
                     zr = value < 2047u ? value : 2047u;   // (anything >= 1024 ends the walk)
                     cnt_a = 0;
@@ -363,7 +383,7 @@ __global__ __launch_bounds__(64, 3) void lossy_decode_kernel(LossyDecArgs D) {
                     wave_sync();
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
-                        const uint8_t *v = sp + vp[u];
+                        const uint8_t *v = lsp + vp[u];
                         for (uint32_t i = 0; i < n[u]; i++) q[o[u] + i] = (short)rd_u16(v + 2 * i);
                     }
                 } else {
@@ -466,30 +486,29 @@ __global__ __launch_bounds__(64, 3) void lossy_decode_kernel(LossyDecArgs D) {
         return true;
     };
 
-    for (uint32_t c = 0; c < (uint32_t)D.channels; c++) {
+    {
 #pragma unroll
         for (int k = 0; k < 16; k++) pv[k] = 0.0f;
-        fetch(h0);
+        if (!index_run(c)) return;
+        fetch(c, h0);
         for (unsigned h = h0; h <= h1; h++) {
-            const uint32_t len = s_flen[h - h0];
-            bool ok;
-            if (len <= (uint32_t)kBlobStage) {
+            const uint32_t blen = s_blen[h - h0];
+            const bool present = s_flag[h - h0] != 0u;
+            const bool staged = present && blen <= (uint32_t)kBlobStage;
+            const uint32_t sfw = pre_sfw;
+            if (staged) {
 #pragma unroll
                 for (int j = 0; j < kPre; j++) {
-                    if (256u * (uint32_t)j < len) {   // uniform
+                    if (256u * (uint32_t)j < blen) {   // uniform
                         const uint32_t i = 4u * ((uint32_t)lane + 64u * (uint32_t)j);
-                        if (i < len) *reinterpret_cast<uint32_t *>(sblob + i) = pre[j];
+                        if (i < blen) *reinterpret_cast<uint32_t *>(sblob + i) = pre[j];
                     }
                 }
                 wave_sync();
-                if (h < h1) fetch(h + 1);
-                DSTAMP(0);
-                ok = frame_ch(c, h, sblob, len, std::true_type{});
-            } else {
-                if (h < h1) fetch(h + 1);
-                ok = frame_ch(c, h, D.bytes + s_foff[h - h0], len, std::false_type{});
             }
-            if (!ok) return;
+            if (h < h1) fetch(c, h + 1);
+            DSTAMP(0);
+            if (!frame_ch(c, h, present, blen, staged, sfw)) return;
         }
     }
 #ifdef FLO_DEC_STAMPS
@@ -736,18 +755,21 @@ __global__ __launch_bounds__(256) void ll_finish_kernel(LlFinishArgs A) {
     } while (0)
 
 int launch_lossy_decode(const LossyDecArgs &A0, unsigned max_frames, hipStream_t s) {
-    if (max_frames < 2 || !A0.n_clips) return 0;
+    if (max_frames < 2 || !A0.n_clips || A0.channels < 1) return 0;
     LossyDecArgs A = A0;
     // a run of R blocks decodes R + 1 frames: long runs waste less, short ones give a single file enough wavefronts
     const unsigned long long blocks = (unsigned long long)A.n_clips * (max_frames - 1);
     A.run = blocks >= 8ull * 4096ull ? kDecRunLong : kDecRunShort;
     const unsigned runs = (max_frames - 1 + (unsigned)A.run - 1) / (unsigned)A.run;
+    A.n_runs = runs;
+    const unsigned long long pairs = ((unsigned long long)A.n_clips * runs + 7ull) / 8ull * 8ull, wgs = pairs * (unsigned)(A.channels > 0 ? A.channels : 1);
+    if (wgs > 0x7FFFFFFFull) return -1;
 #ifdef FLO_DEC_STAMPS
     unsigned long long *d_dbg = nullptr;
     if (hipMalloc(&d_dbg, 80) != hipSuccess || hipMemset(d_dbg, 0, 80) != hipSuccess) return -1;
     A.dbg = d_dbg;
 #endif
-    hipLaunchKernelGGL(lossy_decode_kernel, dim3((unsigned)A.n_clips, runs), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(lossy_decode_kernel, dim3((unsigned)wgs), dim3(64), 0, s, A);
     FLO_LAUNCH_CHECK();
 #ifdef FLO_DEC_STAMPS
     {

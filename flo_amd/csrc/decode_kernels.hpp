@@ -22,6 +22,7 @@ struct LossyDecArgs {
     float *out;                       // (frames - 1) * 1024 * channels floats per clip, every one written
     int *error;                       // set to 1 when a frame cannot be deserialised
     int run;                          // output blocks per wavefront (set by the launcher)
+    unsigned int n_runs;              // runs per clip (set by the launcher)
     unsigned long long *dbg;          // FLO_DEC_STAMPS builds only: phase tick sums (set by the launcher)
 };
 
