@@ -360,7 +360,7 @@ __device__ __forceinline__ unsigned wave_scan_add_dpp(unsigned v) {
 
 // One wrapper by the whole wavefront: fixed predictors, raw and silent wrappers, LPC wrappers without a recurrence to run
 // (ll_predict_kernel takes the others four at a time in rows, see predict_rows).
-__device__ __noinline__ void predict_one(const LlParArgs &A, const unsigned chi, const int lane, double *cs) {
+__device__ __forceinline__ void predict_one(const LlParArgs &A, const unsigned chi, const int lane, double *cs) {
     if (A.serial[chi]) return;
     const LlChannelDev c = A.ch[chi];
     int *r = A.scratch + c.out_off;
