@@ -812,7 +812,15 @@ __global__ __launch_bounds__(128) void an_fft_kernel(AnalysisArgs A) {
     }
 }
 
-int launch_analysis(const AnalysisArgs &A, hipStream_t s) {
+int launch_analysis(const AnalysisArgs &A, hipStream_t s, const AnalysisSide *side) {
+    // s0: peaks of the waveform + K-weighting; s1: true / sample peak; s2: sum of squares; s3: BLAKE3 + spectrum
+    hipStream_t s1 = s, s2 = s, s3 = s;
+    if (side && A.n) {
+        if (hipEventRecord(side->fork, s) != hipSuccess) return -1;
+        for (int i = 0; i < 3; i++)
+            if (hipStreamWaitEvent(side->st[i], side->fork, 0) != hipSuccess) return -1;
+        s1 = side->st[0], s2 = side->st[1], s3 = side->st[2];
+    }
     if (A.n_peaks) {
         hipLaunchKernelGGL(an_peaks_kernel, dim3(A.n_peaks), dim3(64), 0, s, A);
         AN_LAUNCH_CHECK();
@@ -827,34 +835,37 @@ int launch_analysis(const AnalysisArgs &A, hipStream_t s) {
             AN_LAUNCH_CHECK();
             const unsigned long long longest = (A.n + A.channels - 1) / A.channels;
             const unsigned tiles = (unsigned)((longest + kAnTile - 1) / kAnTile);
-            hipLaunchKernelGGL(an_peak_kernel, dim3(tiles, A.channels), dim3(256), 0, s, A);
+            hipLaunchKernelGGL(an_peak_kernel, dim3(tiles, A.channels), dim3(256), 0, s1, A);
             AN_LAUNCH_CHECK();
-            hipLaunchKernelGGL(an_peak_reduce_kernel, dim3(1), dim3(256), 0, s, A, (unsigned long long)tiles * A.channels);
+            hipLaunchKernelGGL(an_peak_reduce_kernel, dim3(1), dim3(256), 0, s1, A, (unsigned long long)tiles * A.channels);
             AN_LAUNCH_CHECK();
         } else {
             hipLaunchKernelGGL(an_loud_kernel, dim3(A.n_seg, A.channels), dim3(128), 0, s, A);
             AN_LAUNCH_CHECK();
         }
         if (A.sq_exact) {
-            hipLaunchKernelGGL(an_sq_dsum_kernel, dim3((unsigned)A.n_sq_chunks), dim3(64), 0, s, A);
+            hipLaunchKernelGGL(an_sq_dsum_kernel, dim3((unsigned)A.n_sq_chunks), dim3(64), 0, s2, A);
             AN_LAUNCH_CHECK();
-            hipLaunchKernelGGL(an_sq_prefix_kernel, dim3(1), dim3(256), 0, s, A);
+            hipLaunchKernelGGL(an_sq_prefix_kernel, dim3(1), dim3(256), 0, s2, A);
             AN_LAUNCH_CHECK();
-            hipLaunchKernelGGL(an_sq_terms_kernel, dim3((unsigned)A.n_sq_chunks), dim3(64), 0, s, A);
+            hipLaunchKernelGGL(an_sq_terms_kernel, dim3((unsigned)A.n_sq_chunks), dim3(64), 0, s2, A);
             AN_LAUNCH_CHECK();
-            hipLaunchKernelGGL(an_sq_chain_kernel, dim3(1), dim3(64), 0, s, A);
+            hipLaunchKernelGGL(an_sq_chain_kernel, dim3(1), dim3(64), 0, s2, A);
             AN_LAUNCH_CHECK();
         } else {
-            hipLaunchKernelGGL(an_sumsq_kernel, dim3(A.n_sq_seg), dim3(64), 0, s, A);
+            hipLaunchKernelGGL(an_sumsq_kernel, dim3(A.n_sq_seg), dim3(64), 0, s2, A);
             AN_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(an_blake3_chunks_kernel, dim3((unsigned)((A.n_chunks + 127) / 128)), dim3(128), 0, s, A);
+        hipLaunchKernelGGL(an_blake3_chunks_kernel, dim3((unsigned)((A.n_chunks + 127) / 128)), dim3(128), 0, s3, A);
         AN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(an_blake3_tree_kernel, dim3(1), dim3(256), 0, s, A);
+        hipLaunchKernelGGL(an_blake3_tree_kernel, dim3(1), dim3(256), 0, s3, A);
         AN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(an_fft_kernel, dim3(3), dim3(128), 0, s, A);
+        hipLaunchKernelGGL(an_fft_kernel, dim3(3), dim3(128), 0, s3, A);
         AN_LAUNCH_CHECK();
     }
+    if (side && A.n)
+        for (int i = 0; i < 3; i++)
+            if (hipEventRecord(side->join[i], side->st[i]) != hipSuccess || hipStreamWaitEvent(s, side->join[i], 0) != hipSuccess) return -1;
     return 0;
 }
 

@@ -52,6 +52,13 @@ struct AnalysisArgs {
     unsigned int *peak_bin;      // [3][8]
 };
 
-int launch_analysis(const AnalysisArgs &A, hipStream_t s);
+// The analysis is four independent chains of kernels - K-weighting, sum of squares, BLAKE3, peaks - each ending in a step
+// that one wavefront walks alone (0.4 - 1 ms for a 3-minute clip). With `side` streams given they run side by side: fork
+// behind what `s` holds at the call, join before the call returns (everything later on `s` sees all results).
+struct AnalysisSide {
+    hipStream_t st[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+};
+int launch_analysis(const AnalysisArgs &A, hipStream_t s, const AnalysisSide *side = nullptr);
 
 }  // namespace flo

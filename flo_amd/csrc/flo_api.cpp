@@ -57,6 +57,8 @@ struct flo_ctx {
     Stager *stager = nullptr;   // pinned staging ring + copy threads of the host-buffer entry points (made on first use)
     hipStream_t up_stream = nullptr, down_stream = nullptr;   // uploads / downloads of flo_encode_batch's pipeline
     int reserve_cus = -1;   // compute units the persistent chain kernel leaves free (-1: not set; see flo_ctx_reserve_cus)
+    AnalysisSide an_side;   // side streams of the analysis (made on first use)
+    bool an_side_ready = false;
 };
 static const int kDefaultReservedCus = 8;
 
@@ -141,6 +143,11 @@ extern "C" void flo_ctx_destroy(flo_ctx *c) {
     if (c->stager) stager_destroy(c->stager);
     if (c->up_stream) hipStreamDestroy(c->up_stream);
     if (c->down_stream) hipStreamDestroy(c->down_stream);
+    if (c->an_side.fork) hipEventDestroy(c->an_side.fork);
+    for (int i = 0; i < 3; i++) {
+        if (c->an_side.join[i]) hipEventDestroy(c->an_side.join[i]);
+        if (c->an_side.st[i]) hipStreamDestroy(c->an_side.st[i]);
+    }
     delete c;
 }
 
@@ -2549,7 +2556,17 @@ static int analyze_impl(flo_ctx *c, const float *pcm, const float *pcm_dev, size
     A.sq_rec = (double *)(rb + o_sqr);
     A.peak_part = (double *)(rb + o_pkp);
     A.cvs = d_cvs.as<unsigned int>();
-    rc = timed_launch(c, "analysis", [&] { return launch_analysis(A, c->stream); });
+    if (!c->an_side_ready && !getenv("FLO_ANALYSIS_ONE_STREAM")) {
+        HIPCHK(c, hipEventCreateWithFlags(&c->an_side.fork, hipEventDisableTiming));
+        for (int i = 0; i < 3; i++) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->an_side.st[i], hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->an_side.join[i], hipEventDisableTiming));
+        }
+        c->an_side_ready = true;
+    }
+    rc = timed_launch(c, "analysis", [&] { return launch_analysis(A, c->stream, c->an_side_ready ? &c->an_side : nullptr); });
+    if (rc != FLO_OK && c->an_side_ready)   // (a failed launch may have left a side stream unjoined: the buffers below must outlive it)
+        for (int i = 0; i < 3; i++) hipStreamSynchronize(c->an_side.st[i]);
     if (rc != FLO_OK) {
         hipStreamSynchronize(c->stream);
         return rc;
