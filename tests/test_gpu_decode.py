@@ -371,3 +371,32 @@ def test_random_damage_decodes_like_the_oracle_or_fails_like_it(ctx):
             diff = np.abs(want[fin].astype(np.float64) - got[fin].astype(np.float64))
             tol = 2e-6 * max(1.0, float(np.abs(want[fin]).max()) if fin.any() else 1.0) if f.is_lossy else 0.0
         assert (float(diff.max()) if diff.size else 0.0) <= tol, (it, f.is_lossy)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ch,lens", [(2, [3, 50000, 1024, 441000, 2047, 90000, 12345]), (1, [70000, 5, 2048, 33333, 1, 100000, 7, 4096, 65536]),
+                                     (2, [1000] * 17), (1, [44100] * 9)])
+def test_ragged_batches_decode_like_their_files(ctx, ch, lens):
+    """The batch decoder deals (clip, run, channel) triples to workgroups in groups of eight per channel (the channels
+    of a run share an XCD): clip counts that are no multiple of eight, clips of one frame next to clips of hundreds, mono
+    and stereo - every clip of the batch must come out exactly as the single-file decoder returns its file."""
+    import torch
+    sr = 44100
+    b = flo_amd.Batch(ctx, flo_amd.MODE_LOSSY, [n * ch for n in lens], sr, ch, 0.55)
+    b.fill_synthetic(seed=0xF10A0D10, clip_id0=77)
+    b.encode(0)
+    b.sync()
+    hops = [(n + 1024 + 1023) // 1024 for n in lens]
+    total = sum(max(h - 1, 0) * 1024 * ch for h in hops)
+    out = torch.full((total + 8,), float("nan"), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    offs = b.decode_to(out.data_ptr(), total)
+    host = out.cpu().numpy()
+    assert np.isnan(host[total:]).all()                      # nothing behind the batch is touched
+    assert not np.isnan(host[:total]).any()                  # every sample of every block is written
+    for i, h in enumerate(hops):
+        want = ctx.decode(b.fetch(i))
+        n_out = max(h - 1, 0) * 1024 * ch
+        assert want.size == n_out, (i, want.size, n_out)
+        np.testing.assert_array_equal(host[offs[i]: offs[i] + n_out], want, err_msg=f"clip {i}")
+    b.close()
