@@ -717,6 +717,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
                 st_sum[13] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
                              ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32) | ((unsigned long long)cl << 40);
                 for (int i = 0; i < 14; i++) A.dbg_stamps[((unsigned long long)clip * 2 + 1) * 16 + i] = st_sum[i];
+                A.dbg_stamps[((unsigned long long)clip * 2 + 1) * 16 + 14] = __builtin_amdgcn_s_memrealtime();   // when the clip's bytes were out
             }
 #endif
             fbase += hops;
@@ -898,6 +899,7 @@ __global__ __launch_bounds__(FLO_C2X_THREADS) void lossy_chain2q_kernel(LossyArg
             st_sum[13] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) |
                          ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) << 32) | ((unsigned long long)cl << 40);
             for (int i = 0; i < 14; i++) A.dbg_stamps[((unsigned long long)clip * 2) * 16 + i] = st_sum[i];
+            A.dbg_stamps[((unsigned long long)clip * 2) * 16 + 14] = __builtin_amdgcn_s_memrealtime();   // when the clip's last frame left the transform wave (100 MHz)
         }
 #endif
         fbase += hops;
