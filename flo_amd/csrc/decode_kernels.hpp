@@ -60,6 +60,8 @@ struct LlParArgs {
     int *serial;                      // [n_ch] nonzero: the serial kernel decodes this wrapper (set by the host for
                                       // k > 14 or large coefficients, by the device for a 256-ones escape or a sample
                                       // outside i32)
+    const unsigned int *others;       // [n_others] the wrappers that are no LPC recurrence (fixed predictors, raw, silent, too short): one
+    unsigned int n_others;            // workgroup each in ll_predict behind the LPC groups (a workgroup per wrapper cost 0.2 ms in dispatch alone)
 };
 // Per frame: mid/side, interleave, int -> float.
 struct LlFrameDev {

@@ -1431,6 +1431,7 @@ static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes,
     // 53 bits) go to the serial kernel
     std::vector<unsigned int> tile0(w.chs.size() + 1, 0);
     std::vector<int> serial(w.chs.size(), 0);
+    std::vector<unsigned int> others;
     unsigned max_tiles = 0;
     const bool force_serial = getenv("FLO_LL_DECODE_SERIAL") != nullptr;
     for (size_t i = 0; i < w.chs.size(); i++) {
@@ -1440,6 +1441,7 @@ static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes,
         for (unsigned q = 0; q < d.n_coeffs; q++) csum += d.coeffs[q] < 0 ? -(long long)d.coeffs[q] : (long long)d.coeffs[q];
         if (force_serial || (rice && d.rice_k > kRiceMaxK) || csum >= (1ll << 21) || (d.n_coeffs && (d.shift_bits & 63u) > 20u)) serial[i] = 1;
         if (rice && d.len > 16u * 1024u * (unsigned)kRiceTileBits) serial[i] = 1;   // the tile stages put a wrapper's tiles (four per workgroup at least) in gridDim.y (<= 65535)
+        if (!(d.n_coeffs > 0 && d.n_coeffs <= 12 && d.len > 0 && d.samples > d.n_coeffs)) others.push_back((unsigned)i);   // (what ll_predict's row form does not take)
         const unsigned nt = rice && !serial[i] ? (d.len + (unsigned)kRiceTileBits / 8u - 1u) / ((unsigned)kRiceTileBits / 8u) : 0u;
         tile0[i + 1] = tile0[i] + nt;
         if (nt > max_tiles) max_tiles = nt;
@@ -1460,7 +1462,8 @@ static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes,
     // of pageable vectors each held the host until the driver had staged them: 0.15 ms of an idle device per call)
     auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_ch = 0, o_fr = up256(w.chs.size() * sizeof(LlChannelDev)), o_t0 = o_fr + up256(w.frs.size() * sizeof(LlFrameDev)),
-                 o_ser = o_t0 + up256(tile0.size() * sizeof(unsigned int)), desc_bytes = o_ser + up256(serial.size() * sizeof(int));
+                 o_ser = o_t0 + up256(tile0.size() * sizeof(unsigned int)), o_oth = o_ser + up256(serial.size() * sizeof(int)),
+                 desc_bytes = o_oth + up256(others.size() * sizeof(unsigned int));
     if ((rc = ctx_stager(c)) != FLO_OK) return rc;
     {
         std::string perr;
@@ -1470,6 +1473,7 @@ static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes,
         memcpy(pin + o_fr, w.frs.data(), w.frs.size() * sizeof(LlFrameDev));
         memcpy(pin + o_t0, tile0.data(), tile0.size() * sizeof(unsigned int));
         memcpy(pin + o_ser, serial.data(), serial.size() * sizeof(int));
+        memcpy(pin + o_oth, others.data(), others.size() * sizeof(unsigned int));
         HIPCHK(c, pool_alloc(&d_desc.p, desc_bytes));
         HIPCHK(c, hipMemcpyAsync(d_desc.p, pin, desc_bytes, hipMemcpyHostToDevice, c->stream));   // (read before this function's final synchronise)
     }
@@ -1477,6 +1481,7 @@ static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes,
     LlFrameDev *const d_fr = reinterpret_cast<LlFrameDev *>(d_desc.as<uint8_t>() + o_fr);
     unsigned int *const d_t0 = reinterpret_cast<unsigned int *>(d_desc.as<uint8_t>() + o_t0);
     int *const d_ser = reinterpret_cast<int *>(d_desc.as<uint8_t>() + o_ser);
+    const unsigned int *const d_oth = reinterpret_cast<const unsigned int *>(d_desc.as<uint8_t>() + o_oth);
     const size_t tiles = tile0.back();
     hipError_t e = pool_alloc(&d_scr.p, w.scratch ? w.scratch * sizeof(int) : 16);
     if (e == hipSuccess) e = pool_alloc(&d_tabs.p, tiles ? tiles * kRiceStates * sizeof(unsigned int) : 16);
@@ -1489,7 +1494,7 @@ static int ll_decode_device(flo_ctx *c, const LlWork &w, const uint8_t *d_bytes,
     if (e == hipSuccess && d_out && partial) e = hipMemsetAsync(d_out, 0, n_out * sizeof(float), c->stream);
     if (e == hipSuccess && d_out_i32 && partial) e = hipMemsetAsync(d_out_i32, 0, n_out * sizeof(int), c->stream);
     if (e != hipSuccess) return fail(c, FLO_ERR_NOMEM, std::string("decode buffers: ") + hipGetErrorString(e));
-    LlParArgs P{d_bytes, d_ch, (unsigned)w.chs.size(), d_scr.as<int>(), d_t0, d_tabs.as<unsigned int>(), d_ent.as<uint2>(), d_ser};
+    LlParArgs P{d_bytes, d_ch, (unsigned)w.chs.size(), d_scr.as<int>(), d_t0, d_tabs.as<unsigned int>(), d_ent.as<uint2>(), d_ser, d_oth, (unsigned)others.size()};
     rc = timed_launch(c, "ll_decode_parallel", [&] { return launch_ll_decode_parallel(P, max_tiles, c->stream); });
     if (rc != FLO_OK) return rc;
     LlDecArgs A{d_bytes, d_ch, (unsigned)w.chs.size(), d_scr.as<int>(), d_ser};

@@ -435,12 +435,16 @@ __device__ __forceinline__ void predict_one(const LlParArgs &A, const unsigned c
 // Four LPC wrappers per wavefront, one per row of sixteen lanes - the same transposed recurrence, but a finished sample
 // reaches the row's other accumulators inside the multiply-add itself: v_fmac_f64 takes its first operand through DPP
 // (row_newbcast:t = lane t of every row), so a step is v_floor_f64 + v_fmac_f64_dpp, no v_readlane and no scalar
-// registers in the loop (the 64-lane form spends floor + 2 readlane + fma on ONE wrapper's step). A row's sixteen
-// accumulators cover taps up to 16 - Q, where Q is how many lanes are collected and re-armed together (a lane's
-// accumulator is final after its own step and receives the next block's first contribution 16 - order steps later):
-// Q = 8 for orders <= 8, Q = 4 for orders <= 12 (the format's maximum). Residuals are fetched a super-block of
-// 16 x 16 samples ahead, so no step waits for memory.
-template <int Q>
+// registers in the loop (the 64-lane form spends floor + 2 readlane + fma on ONE wrapper's step).
+// TWO accumulators per lane: `cur` holds the prediction of sample l of the block being stepped, `nxt` that of sample l of
+// the block behind it. Step t adds sample t's contribution to the later lanes of its own block (taps l - t - 1, l > t,
+// into `cur` - the dependent chain) and, in the last MAXO steps, to the first lanes of the next block (taps
+// 16 + l - t - 1 into `nxt` - a second multiply-add off the chain). At the block's end every lane's `cur` is its sample
+// (one floor for all sixteen), `nxt` becomes `cur`, and the old `cur` register is read out and armed with the residuals of
+// the block after next during the first steps of the next block.
+// MAXO = 8 or 12 (the format's maximum): how many steps need the second multiply-add. Residuals are fetched a super-block
+// of 16 x 16 samples ahead, so no step waits for memory.
+template <int MAXO>
 __device__ __forceinline__ void predict_rows(const LlParArgs &A, const unsigned chi, const int lane, double *cs, const bool act) {
     // (a row without an LPC wrapper of its own - `act` false - runs along on zeros and touches no memory)
     const int rl = lane & 15, row0 = lane & 48;
@@ -450,12 +454,19 @@ __device__ __forceinline__ void predict_rows(const LlParArgs &A, const unsigned 
     const int order = act ? (int)cd->n_coeffs : 0;
     const uint32_t sh = cd->shift_bits & 63u;
     wave_sync_l();
-    cs[lane] = rl < order ? ldexp((double)cd->coeffs[rl], -(int)sh) : 0.0;
+    cs[lane] = rl < order ? ldexp((double)cd->coeffs[rl], -(int)sh) : 0.0;   // (entries order .. 15 are 0: order <= 12)
     wave_sync_l();
-    double C[16];   // C[t][lane] = tap (rl - t - 1) mod 16 of the row's wrapper
+    // C1[t][lane]: what sample t adds to sample `lane` of its own block (tap lane - t - 1 for lane > t);
+    // C2[t][lane]: ... to sample `lane` of the next block (tap 16 + lane - t - 1, only for the last MAXO steps)
+    double C1[16], C2[MAXO];
 #pragma unroll
-    for (int t = 0; t < 16; t++) C[t] = cs[row0 + ((rl - t - 1) & 15)];
-    double acc;
+    for (int t = 0; t < 16; t++) C1[t] = rl > t ? cs[row0 + (rl - t - 1)] : 0.0;
+#pragma unroll
+    for (int u = 0; u < MAXO; u++) {
+        const int t = 16 - MAXO + u, k = 16 + rl - t - 1;   // k >= rl
+        C2[u] = k < 16 ? cs[row0 + k] : 0.0;
+    }
+    double accA, accB = 0.0;
     {
         long long v = (uint32_t)rl < n ? (long long)r[rl] : 0;
         if (rl < order) {   // the first `order` samples are their residuals: take the loop's prediction off beforehand
@@ -463,7 +474,7 @@ __device__ __forceinline__ void predict_rows(const LlParArgs &A, const unsigned 
             for (int j = 0; j < rl; j++) pred += (long long)cd->coeffs[j] * (long long)r[rl - 1 - j];
             v -= pred >> sh;
         }
-        acc = (double)v;
+        accA = (double)v;
     }
     // wave-uniform block count: the longest of the four wrappers (a shorter one runs on over zero residuals, unstored)
     uint32_t nmax = n;
@@ -475,12 +486,19 @@ __device__ __forceinline__ void predict_rows(const LlParArgs &A, const unsigned 
     }
     nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
     const uint32_t nb = (nmax + 15u) >> 4;
+    uint32_t nmin = 0xFFFFFFFFu;   // the shortest of the wrappers the wavefront really has
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)(act ? n : 0xFFFFFFFFu), 16 * k);
+        nmin = o < nmin ? o : nmin;
+    }
     // Memory is touched at ONE point per super-block of kSb blocks: wait for what was issued a super-block ago (the
     // residuals of this one, the samples of the one before - both long complete), then issue the next residual loads
     // and the finished samples' stores, then run kSb x 16 steps on registers. (Loads and stores inside the stepping
     // loop made the compiler wait for all outstanding memory operations at every block: the loop-carried count is
     // unknown to it, and a block then cost a memory round trip.)
     constexpr int kSb = 16;
+    static_assert(kSb % 2 == 0, "the two accumulators swap roles block by block");
     auto fetch = [&](int (&buf)[kSb], const uint32_t b0) {
 #pragma unroll
         for (int j = 0; j < kSb; j++) {
@@ -488,50 +506,92 @@ __device__ __forceinline__ void predict_rows(const LlParArgs &A, const unsigned 
             buf[j] = i < n ? r[i] : 0;
         }
     };
+#ifdef FLO_PRED_DBG
+    const unsigned long long dbg_t0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     int pf[kSb], outs[kSb];
-    fetch(pf, 1u);
+    fetch(pf, 1u);   // (while block b is stepped, the other accumulator is armed with the residuals of block b + 1)
 #pragma unroll
     for (int j = 0; j < kSb; j++) outs[j] = 0;
-    double outv = 0.0, worst = 0.0;
-    for (uint32_t sb = 0; (uint32_t)kSb * sb < nb + (uint32_t)kSb; sb++) {   // (one extra round stores the last super-block)
+    double worst = 0.0;
+    // One block: `cur` is stepped; `nxt` still holds the finished block before this one - its samples are read out and
+    // the register is re-armed with `rn` (the residuals of the block behind this one) in the first four steps, one
+    // instruction per step in the two wait states a DPP read needs behind the floor anyway (in program order behind
+    // the block they stalled the wave: floor -> conversion -> maximum are a dependent chain of their own, and a wave
+    // issues in order). The largest magnitude is checked once, behind the loop (v_cvt saturates meanwhile; a wrapper
+    // that leaves the i32 range is decoded again by the serial kernel, so what is stored for it does not matter). Lanes
+    // behind a shorter wrapper's end run on over zero residuals and are counted too: at worst a needless serial decode.
+    // (A NaN can only follow a finite value beyond the range, which is recorded.)
+    auto block = [&](double &cur, double &nxt, const int rn, int &out_prev) {
+        double x, sv;
+        asm("v_floor_f64 %1, %0\n\tv_floor_f64 %2, %3\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %1, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf"
+            : "+v"(cur), "=&v"(x), "=&v"(sv)
+            : "v"(nxt), "v"(C1[0]));
+        asm("v_floor_f64 %1, %0\n\tv_cvt_i32_f64 %2, %3\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %1, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf"
+            : "+v"(cur), "=&v"(x), "=&v"(out_prev)
+            : "v"(sv), "v"(C1[1]));
+        asm("v_floor_f64 %1, %0\n\tv_max_f64 %2, %2, |%3|\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf"
+            : "+v"(cur), "=&v"(x), "+v"(worst)
+            : "v"(sv), "v"(C1[2]));
+        asm("v_floor_f64 %1, %0\n\tv_cvt_f64_i32 %2, %3\n\ts_nop 0\n\tv_fmac_f64_dpp %0, %1, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+            : "+v"(cur), "=&v"(x), "=&v"(nxt)
+            : "v"(rn), "v"(C1[3]));
+#pragma unroll
+        for (int t = 4; t < 16; t++) {
+            // (two wait states between a VALU write and a DPP read of the same register)
+            if (t < 16 - MAXO) {
+                asm("v_floor_f64 %1, %0\n\ts_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                    : "+v"(cur), "=&v"(x)
+                    : "v"(C1[t]), "n"(t));
+            } else {
+                asm("v_floor_f64 %2, %0\n\ts_nop 1\n\tv_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+                    : "+v"(cur), "+v"(nxt), "=&v"(x)
+                    : "v"(C1[t]), "v"(C2[t < 16 - MAXO ? 0 : t - (16 - MAXO)]), "n"(t));
+            }
+        }
+    };
+    static_assert(MAXO <= 12, "the other accumulator is re-armed in step 3: its first contribution comes in step 16 - MAXO");
+    // blocks 0 .. nb: block nb is a dummy whose first steps read block nb - 1 out. outs[j] of super-block sb belongs to
+    // block kSb sb + j - 1.
+    for (uint32_t sb = 0; (uint32_t)kSb * sb < nb + 1u + (uint32_t)kSb; sb++) {   // (one extra round stores the last super-block)
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         int cur[kSb];
 #pragma unroll
         for (int j = 0; j < kSb; j++) cur[j] = pf[j];
-        fetch(pf, (uint32_t)kSb * (sb + 1u) + 1u);
-        if (sb > 0) {
+        // (inside every wrapper of the wavefront - all super-blocks but the first two and the last - the sixteen loads and
+        // stores are plain accesses at constant offsets from one address each, under one exec mask for the rows that have a
+        // wrapper; with an index test and a branch per element they were 500 instructions per super-block, a third of the loop)
+        if (sb >= 2u && 16u * ((uint32_t)kSb * (sb + 1u) + (uint32_t)kSb + 1u) <= nmin) {   // (uniform)
+            if (act) {
+                const int *rp = r + 16u * ((uint32_t)kSb * (sb + 1u) + 1u) + (uint32_t)rl;
+                int *wp = r + 16u * ((uint32_t)kSb * (sb - 1u) - 1u) + (uint32_t)rl;
 #pragma unroll
-            for (int j = 0; j < kSb; j++) {
-                const uint32_t i = 16u * ((uint32_t)kSb * (sb - 1u) + (uint32_t)j) + (uint32_t)rl;
-                if (i < n) r[i] = outs[j];
+                for (int j = 0; j < kSb; j++) pf[j] = rp[16 * j];
+#pragma unroll
+                for (int j = 0; j < kSb; j++) wp[16 * j] = outs[j];
             }
-        }
-        if ((uint32_t)kSb * sb >= nb) break;
+        } else {
+            fetch(pf, (uint32_t)kSb * (sb + 1u) + 1u);
+            if (sb > 0) {
 #pragma unroll
-        for (int j = 0; j < kSb; j++) {
-            const double rn = (double)cur[j];
-#pragma unroll
-            for (int t = 0; t < 16; t++) {
-                double x;
-                // (two wait states between a VALU write and a DPP read of the same register)
-                asm("v_floor_f64 %1, %0\n\ts_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                    : "+v"(acc), "=&v"(x)
-                    : "v"(C[t]), "n"(t));
-                if (t % Q == Q - 1) {
-                    const bool mine = rl / Q == t / Q;
-                    outv = mine ? acc : outv;
-                    acc = mine ? rn : acc;
+                for (int j = 0; j < kSb; j++) {
+                    const uint32_t i = 16u * ((uint32_t)kSb * (sb - 1u) + (uint32_t)j - 1u) + (uint32_t)rl;   // (block -1: beyond n, nothing stored)
+                    if (i < n) r[i] = outs[j];
                 }
             }
-            // The largest magnitude is checked once, behind the loop (v_cvt saturates meanwhile; a wrapper that leaves the
-            // i32 range is decoded again by the serial kernel, so what is stored for it does not matter). Lanes behind a
-            // shorter wrapper's end run on over zero residuals and are counted too: at worst a needless serial decode.
-            const double sv = floor(outv);
-            worst = fmax(worst, fabs(sv));   // (a NaN can only follow a finite value beyond the range, which is recorded)
-            outs[j] = (int)sv;
+        }
+        if ((uint32_t)kSb * sb >= nb + 1u) break;
+#pragma unroll
+        for (int j = 0; j < kSb; j += 2) {
+            block(accA, accB, cur[j], outs[j]);
+            block(accB, accA, cur[j + 1], outs[j + 1]);
         }
     }
     const bool bad = !(worst < 2147483648.0);
+#ifdef FLO_PRED_DBG
+    if (lane == 0 && (blockIdx.x == 7 || (__builtin_amdgcn_s_memrealtime() - dbg_r0) > 110000ull)) printf("rows wg %u: nb %u cycles %llu realtime(100MHz) %llu\n", blockIdx.x, nb, (unsigned long long)(__builtin_readcyclecounter() - dbg_t0), (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_r0));
+#endif
     if (bad) A.serial[chi] = 1;
 }
 
@@ -544,8 +604,9 @@ __device__ __forceinline__ bool takes_rows(const LlParArgs &A, const unsigned ch
     return order > 0 && order <= 12 && cd->len > 0 && cd->samples > (uint32_t)order;
 }
 
-// Workgroups [0, ceil(n_ch / 4)): the LPC wrappers, four per wavefront; workgroups behind them: one per wrapper for
-// everything else (fixed predictors, raw, silent), so a frame's fixed-predictor channel never waits behind a recurrence.
+// Workgroups [0, ceil(n_ch / 4)): the LPC wrappers, four per wavefront; workgroups behind them: one per wrapper of the
+// host's list of everything else (fixed predictors, raw, silent), so a frame's fixed-predictor channel never waits behind
+// a recurrence.
 __global__ __launch_bounds__(64) void ll_predict_kernel(LlParArgs A) {
     __shared__ double cs[64];
     const int lane = (int)threadIdx.x;
@@ -556,11 +617,19 @@ __global__ __launch_bounds__(64) void ll_predict_kernel(LlParArgs A) {
         const bool rows = takes_rows(A, chi, order);
         if (__ballot(rows) == 0ull) return;
         if (__ballot(rows && order > 8) == 0ull) predict_rows<8>(A, chi, lane, cs, rows);
-        else predict_rows<4>(A, chi, lane, cs, rows);
+        else predict_rows<12>(A, chi, lane, cs, rows);
         return;
     }
-    const unsigned chi = blockIdx.x - groups;   // (uniform)
+    const unsigned oi = blockIdx.x - groups;   // (uniform)
+    if (oi >= A.n_others) return;
+    const unsigned chi = A.others[oi];
+#ifdef FLO_PRED_DBG
+    const unsigned long long dbg_f0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (!takes_rows(A, chi, order)) predict_one(A, chi, lane, cs);
+#ifdef FLO_PRED_DBG
+    if (lane == 0 && (chi == 5 || (__builtin_amdgcn_s_memrealtime() - dbg_f0) > 60000ull)) printf("other wg %u chi %u realtime(100MHz) %llu\n", blockIdx.x, chi, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_f0));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ launcher
@@ -571,7 +640,7 @@ int launch_ll_decode_parallel(const LlParArgs &A, unsigned max_tiles, hipStream_
         hipLaunchKernelGGL(ll_rice_chain_kernel, dim3(A.n_ch), dim3(64), 0, s, A);
         hipLaunchKernelGGL(ll_rice_decode_kernel, dim3(A.n_ch, (max_tiles + 63) / 64), dim3(64), 0, s, A);
     }
-    hipLaunchKernelGGL(ll_predict_kernel, dim3((A.n_ch + 3u) / 4u + A.n_ch), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(ll_predict_kernel, dim3((A.n_ch + 3u) / 4u + A.n_others), dim3(64), 0, s, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     return 0;
