@@ -210,3 +210,27 @@ def test_many_wrappers_in_one_call(ctx):
             ch = [wrapper(residuals(rng, n, k), k, shift=128 + int(rng.integers(0, 5))) for _ in range(2)]
         frames.append((8, n, int(rng.integers(0, 2)), ch))
     same(ctx, flofile.build_lossless(SR, 2, frames))
+
+
+@pytest.mark.parametrize("orders", [(8, 8, 8, 8), (12, 3, 9, 5), (6, 0, 7, 0), (0, 11, 0, 0), (1, 2, 12, 8)])
+def test_long_wrappers_of_unequal_length_share_a_wavefront(ctx, orders):
+    """ll_predict runs four consecutive LPC wrappers in one wavefront, a row of sixteen lanes each: inside every wrapper of
+    the group a super-block's loads and stores are unpredicated, near a wrapper's end they are tested one by one; rows
+    whose wrapper is a fixed predictor (order 0 here) run along idle. Lengths that end inside different super-blocks,
+    orders on both sides of the eight-tap form, and fixed predictors in between must all decode bit for bit."""
+    rng = np.random.default_rng(sum(orders) + 5)
+    lens = [20000, 20001, 9000, 44100]
+    frames = []
+    for rep in range(3):
+        for n in lens:
+            chans = []
+            for c in range(2):
+                order = orders[(2 * len(frames) + c) % 4]
+                k = int(rng.integers(2, 11))
+                if order:
+                    taps = 0.9 * rng.uniform(-1, 1, order) * (0.6 ** np.arange(order))
+                    chans.append(wrapper(residuals(rng, n, k), k, np.rint(taps * 4096).astype(int), 12))
+                else:
+                    chans.append(wrapper(residuals(rng, n, k), k, shift=128 + int(rng.integers(1, 5))))
+            frames.append((8, n, 0, chans))
+    same(ctx, flofile.build_lossless(SR, 2, frames))
