@@ -154,15 +154,17 @@ __global__ __launch_bounds__(64 * kScanWaves) void ll_rice_scan_kernel(LlParArgs
     // bookkeeping than in arithmetic.
     constexpr uint32_t T = (uint32_t)kRiceTileBits;
     const uint32_t kp1 = k + 1u;
+    uint32_t kp1v = kp1, endv = T + kp1;   // (in vector registers: as scalars they were copied into one at every use)
+    asm volatile("" : "+v"(kp1v), "+v"(endv));
     auto step = [&](const uint32_t *w, const bool go, uint32_t &pos, uint32_t &n) {
         // (the two words arrive as one 64-bit register pair, high word first: ds_read2_b32 with its offsets crossed)
         unsigned long long two;
         asm volatile("ds_read2_b32 %0, %1 offset0:1\n\ts_waitcnt lgkmcnt(0)" : "=v"(two) : "v"((uint32_t)(uintptr_t)(w + (pos >> 5))) : "memory");
-        const uint32_t ones = leading_ones((uint32_t)((two << (pos & 31u)) >> 32));
+        const uint32_t ones = (uint32_t)__clz((int)~(uint32_t)((two << (pos & 31u)) >> 32));   // (32 for a window of ones)
         const uint32_t z = pos + ones;                      // the terminating 0, or 32 bits on
         const bool in_tile = z < T;
         const bool term = in_tile && ones < 32u;
-        const uint32_t npos = (in_tile ? z : T + kp1) + (term ? kp1 : 0u);
+        const uint32_t npos = (in_tile ? z : endv) + (term ? kp1v : 0u);
         n += (go && term && npos < T) ? 1u : 0u;
         pos = go ? npos : pos;
     };
