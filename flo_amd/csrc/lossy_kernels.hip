@@ -1305,6 +1305,80 @@ __global__ __launch_bounds__(THREADS) void lossy_frame_offsets_kernel(LossyArgs 
     if (t == THREADS - 1) A.clip_bytes[clip] = wtot[THREADS / 64 - 1];
 }
 
+// Few clips (configs[1]: one of three minutes): frame offsets and packing in ONE launch. A workgroup owns a chunk of
+// kCompactChunk consecutive frames of a clip; it adds up the sizes of the clip's frames in front of its chunk itself
+// (at most a few thousand 4-byte loads, spread over its threads: 31 KB out of the L2 for the last chunk of a 3-minute
+// clip), scans its own frames' sizes and copies their slots to their places. One kernel instead of a one-workgroup scan
+// followed by a copy kernel that waited for it: of the two launches' 17.4 us for a 3-minute clip each had been mostly launch,
+// ramp and drain.
+constexpr int kCompactChunk = 32;
+__global__ __launch_bounds__(256) void lossy_offsets_compact_kernel(LossyArgs A) {
+    __shared__ unsigned long long wsum[4];
+    __shared__ unsigned long long foff[kCompactChunk + 1];
+    const unsigned clip = blockIdx.y;
+    const unsigned hops = A.clip_hops[clip];
+    const unsigned h0 = blockIdx.x * (unsigned)kCompactChunk;
+    if (h0 >= hops && !(hops == 0 && blockIdx.x == 0)) return;   // (uniform)
+    const unsigned long long f0 = A.clip_frame0[clip];
+    const unsigned t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    // bytes in front of the chunk
+    unsigned long long sum = 0;
+    for (unsigned hb = t; hb < h0; hb += 256u * 8u) {
+        uint32_t v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v8[j] = hb + 256u * (unsigned)j < h0 ? A.frame_size[f0 + hb + 256u * (unsigned)j] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) sum += v8[j];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    if (lane == 0) wsum[w] = sum;
+    // the chunk's own sizes: an exclusive scan by the first wave
+    const unsigned nf = hops - h0 < (unsigned)kCompactChunk ? hops - h0 : (unsigned)kCompactChunk;
+    __syncthreads();
+    if (w == 0) {
+        const unsigned long long before = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        const uint32_t mine = lane < nf ? A.frame_size[f0 + h0 + lane] : 0u;
+        unsigned long long v = mine;
+#pragma unroll
+        for (int d = 1; d < kCompactChunk; d <<= 1) {
+            const unsigned long long u = __shfl_up(v, d);
+            if (lane >= (unsigned)d) v += u;
+        }
+        if (lane < nf) {
+            foff[lane] = before + v - mine;
+            A.frame_off[f0 + h0 + lane] = before + v - mine;
+        }
+        if (lane == (nf ? nf - 1 : 0)) {
+            foff[nf] = before + (nf ? v : 0ull);
+            if (h0 + nf >= hops) A.clip_bytes[clip] = before + (nf ? v : 0ull);   // the clip's last chunk knows the total
+        }
+    }
+    __syncthreads();
+    // copy: a frame is a run of bytes at any alignment in the clip's DATA chunk; its slot is 16-byte aligned. Four bytes per
+    // thread and step (global memory takes unaligned dwords), the last one to three byte by byte.
+    // Eight threads per frame, all frames of the chunk at once, four independent dwords per thread and round (one frame
+    // after the other, a round trip per frame, the chunk took 32 memory latencies).
+    uint8_t *const out = A.out + A.out_off[clip];
+    const unsigned j = t >> 3, sub = t & 7u;
+    if (j < nf) {
+        const uint8_t *src = A.slots + (f0 + h0 + j) * (unsigned long long)A.slot_bytes;
+        uint8_t *dst = out + foff[j];
+        const uint32_t len = (uint32_t)(foff[j + 1] - foff[j]);
+        const uint32_t n4 = len >> 2;
+        for (uint32_t i = sub; i < n4; i += 32u) {
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i + 8u * (uint32_t)u < n4) __builtin_memcpy(&v[u], src + 4u * (i + 8u * (uint32_t)u), 4);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i + 8u * (uint32_t)u < n4) __builtin_memcpy(dst + 4u * (i + 8u * (uint32_t)u), &v[u], 4);
+        }
+        if (sub < (len & 3u)) dst[4u * n4 + sub] = src[4u * n4 + sub];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- stage kernels
 // forward MDCT of independent 2048-sample mono windows (flo_mdct_forward)
 __global__ __launch_bounds__(64) void mdct_only_kernel(LossyDevTables T, const float *frames, unsigned long long n,
@@ -1568,6 +1642,12 @@ int launch_lossy_scan(const LossyArgs &A, hipStream_t s) {
     return 0;
 }
 int launch_lossy_compact(const LossyArgs &A, hipStream_t s) {
+    if (A.n_clips <= 16 && !getenv("FLO_COMPACT_TWO_KERNELS")) {   // few clips: the fused form (a chunk's workgroup sums the sizes in front of it itself)
+        const unsigned chunks = ((unsigned)A.max_hops + kCompactChunk - 1) / kCompactChunk;
+        hipLaunchKernelGGL(lossy_offsets_compact_kernel, dim3(chunks ? chunks : 1u, (unsigned)A.n_clips), dim3(256), 0, s, A);
+        FLO_LAUNCH_CHECK();
+        return 0;
+    }
     if (A.n_clips < 64) hipLaunchKernelGGL((lossy_frame_offsets_kernel<1024>), dim3(A.n_clips), dim3(1024), 0, s, A);
     else hipLaunchKernelGGL((lossy_frame_offsets_kernel<256>), dim3(A.n_clips), dim3(256), 0, s, A);
     FLO_LAUNCH_CHECK();
