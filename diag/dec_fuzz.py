@@ -42,7 +42,9 @@ for it in range(N):
         elif want.size:
             with np.errstate(invalid="ignore", over="ignore"):
                 fin = np.isfinite(want) & np.isfinite(got)
-                same_nonfinite = np.array_equal(np.isnan(want), np.isnan(got)) and np.array_equal(np.isposinf(want), np.isposinf(got)) and np.array_equal(np.isneginf(want), np.isneginf(got))
+                # (a damaged scale word can overflow a frame: which of its samples end as inf and which as NaN is a matter of the
+                # FFT's order of operations - the oracle's FFT is not the device's - so only WHERE the result is not finite must agree)
+                same_nonfinite = np.array_equal(np.isfinite(want), np.isfinite(got))
                 diff = np.abs(want[fin].astype(np.float64) - got[fin].astype(np.float64))
             # lossy: 2e-6 absolute on full-scale audio; a damaged scale word can blow a frame up, so relative to the
             # frame's own magnitude (1024-sample-frame blocks)
