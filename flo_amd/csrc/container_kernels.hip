@@ -4,6 +4,7 @@
 // CRC32 (IEEE, reflected, init/xorout 0xFFFFFFFF) of a chunk is computed by all 256 threads of a workgroup at once
 // from the linearity of the CRC register over GF(2) (see finish_files_kernel); products x^k * r mod P are 32-step
 // shift-and-xor loops, the per-stripe skip is a table.
+#include <stdlib.h>
 #include "container_kernels.hpp"
 
 #include <cstring>
@@ -76,12 +77,11 @@ __device__ __forceinline__ unsigned long long slice_bytes(unsigned long long n, 
     return (s + kStripe - 1) / kStripe * kStripe;
 }
 
-__global__ __launch_bounds__(kFinThreads) void crc_slices_kernel(FinishArgs A) {
+__device__ __forceinline__ void crc_slice_body(const FinishArgs &A, const unsigned clip, const unsigned part) {
     __shared__ uint32_t tab[4][256];    // slicing-by-4 byte tables
     __shared__ uint32_t skip[4][256];   // multiplication by x^(8 (kStripe - kBlk))
     __shared__ uint32_t s_red[kFinThreads / 64];
     __shared__ uint32_t s_pw[2];
-    const unsigned clip = blockIdx.x, part = blockIdx.y;   // clips in x: gridDim.y stops at 65535
     if (clip >= (unsigned)A.n_clips) return;
     const unsigned t = threadIdx.x;
     const unsigned long long total = A.clip_bytes[clip];
@@ -155,31 +155,59 @@ __global__ __launch_bounds__(kFinThreads) void crc_slices_kernel(FinishArgs A) {
     }
 }
 
+__global__ __launch_bounds__(kFinThreads) void crc_slices_kernel(FinishArgs A) {
+    crc_slice_body(A, blockIdx.x, blockIdx.y);   // clips in x: gridDim.y stops at 65535
+}
+
+// header (writer.rs:132-191); total_samples (bytes 14 .. 21) comes from the TOC's last chunk
+__device__ __forceinline__ void write_header(const FinishArgs &A, uint8_t *file, const unsigned clip, const unsigned nf, const unsigned long long n,
+                                             const uint32_t crc) {
+    if (A.crc_out) A.crc_out[clip] = crc;
+    uint8_t *p = file;
+    p[0] = 'F'; p[1] = 'L'; p[2] = 'O'; p[3] = '!';
+    put8(p + 4, 1);    // version 1.2 (core/types.rs:12-13)
+    put8(p + 5, 2);
+    put8(p + 6, A.flags & 0xFF);
+    put8(p + 7, A.flags >> 8);
+    put32(p + 8, A.sample_rate);
+    put8(p + 12, A.channels);
+    put8(p + 13, A.bit_depth);
+    put8(p + 22, A.level);
+    put8(p + 23, 0); put8(p + 24, 0); put8(p + 25, 0);
+    put32(p + 26, crc);
+    put64(p + 30, 66);
+    put64(p + 38, 4ull + 20ull * nf);
+    put64(p + 46, n);
+    put64(p + 54, 0);
+    put64(p + 62, 0);    // meta_size: patched by whoever appends a META chunk
+    put32(p + 70, nf);
+}
+
 // THREADS: 256 for batches of many clips, 1024 for a few long ones. The TOC of a long clip is cut into chunks of
 // A.toc_chunk frames, one workgroup each (blockIdx.y): a 3-minute clip has 7752 entries, and one workgroup writing all
 // of them was 20-28 us of a 0.15 ms encode. A chunk's workgroup first adds up the sizes in front of its chunk (strided
 // loads, a block reduction), then scans its own frames; chunk 0 also joins the CRC slices and writes the header, the
 // last chunk the header's total_samples.
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void finish_files_kernel(FinishArgs A) {
+__device__ __forceinline__ void finish_body(const FinishArgs &A, const unsigned clip, const unsigned chunk_idx) {
     __shared__ uint32_t s_red[THREADS / 64];
     __shared__ unsigned long long w_sum[THREADS / 64], w_smp[THREADS / 64], p_sum[THREADS / 64], p_smp[THREADS / 64];
-    const unsigned clip = blockIdx.x;
     if (clip >= (unsigned)A.n_clips) return;
     const unsigned t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     const unsigned nf = A.clip_frames[clip];
     const unsigned chunk = A.toc_chunk ? A.toc_chunk : 0xFFFFFFFFu;
-    const unsigned long long c0l = (unsigned long long)blockIdx.y * chunk;
-    if (c0l >= nf && blockIdx.y != 0) return;   // (an empty clip still gets its header from chunk 0)
+    const unsigned long long c0l = (unsigned long long)chunk_idx * chunk;
+    if (c0l >= nf && chunk_idx != 0) return;   // (an empty clip still gets its header from chunk 0)
     const unsigned c0 = (unsigned)(c0l < nf ? c0l : nf), c1 = (unsigned)(c0l + chunk < nf ? c0l + chunk : nf);
-    const bool first = blockIdx.y == 0, last = c1 == nf;
+    const bool first = chunk_idx == 0, last = c1 == nf;
+    const bool do_crc = A.mode != 1u, do_toc = A.mode != 2u;
     const unsigned long long n = A.clip_bytes[clip];
     uint8_t *file = A.out + A.data_off[clip] - (74ull + 20ull * nf);
     const unsigned long long fb = A.clip_frame0[clip];
 
     // slice registers -> end of the message; thread `parts` adds the initial register carried through all n bytes
     uint32_t acc = 0;
-    if (first) {
+    if (first && do_crc) {
         const unsigned long long S = slice_bytes(n, A.parts);
         if (t < A.parts) {
             const unsigned long long end = (unsigned long long)(t + 1) * S < n ? (unsigned long long)(t + 1) * S : n;
@@ -192,6 +220,15 @@ __global__ __launch_bounds__(THREADS) void finish_files_kernel(FinishArgs A) {
         if (lane == 0) s_red[wv] = acc;
     }
 
+    if (!do_toc) {   // (uniform) CRC and header only
+        __syncthreads();
+        if (first && t == 0) {
+            uint32_t r = 0;
+            for (int k = 0; k < THREADS / 64; k++) r ^= s_red[k];
+            write_header(A, file, clip, nf, n, ~r);
+        }
+        return;
+    }
     // bytes and samples in front of the chunk
     unsigned long long pb = 0, ps = 0;
     for (unsigned f = t; f < c0; f += 4 * THREADS) {
@@ -288,31 +325,24 @@ __global__ __launch_bounds__(THREADS) void finish_files_kernel(FinishArgs A) {
         for (unsigned f = f0 + 8; f < f1; f++) entry(f, A.frame_size[fb + f], A.frame_samples ? A.frame_samples[fb + f] : A.const_samples);
     }
     if (last && t == 0) put64(file + 14, w_smp[THREADS / 64 - 1] + p_smp[0]);   // total_samples = sum of frame_samples
-    if (first && t == 0) {
+    if (first && t == 0 && do_crc) {
         uint32_t r = 0;
         for (int k = 0; k < THREADS / 64; k++) r ^= s_red[k];
-        const uint32_t crc = ~r;
-        if (A.crc_out) A.crc_out[clip] = crc;
-        // header (writer.rs:132-191)
-        uint8_t *p = file;
-        p[0] = 'F'; p[1] = 'L'; p[2] = 'O'; p[3] = '!';
-        put8(p + 4, 1);    // version 1.2 (core/types.rs:12-13)
-        put8(p + 5, 2);
-        put8(p + 6, A.flags & 0xFF);
-        put8(p + 7, A.flags >> 8);
-        put32(p + 8, A.sample_rate);
-        put8(p + 12, A.channels);
-        put8(p + 13, A.bit_depth);
-        put8(p + 22, A.level);
-        put8(p + 23, 0); put8(p + 24, 0); put8(p + 25, 0);
-        put32(p + 26, crc);
-        put64(p + 30, 66);
-        put64(p + 38, 4ull + 20ull * nf);
-        put64(p + 46, n);
-        put64(p + 54, 0);
-        put64(p + 62, 0);    // meta_size: patched by whoever appends a META chunk
-        put32(p + 70, nf);
+        write_header(A, file, clip, nf, n, ~r);
     }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void finish_files_kernel(FinishArgs A) {
+    finish_body<THREADS>(A, blockIdx.x, blockIdx.y);
+}
+
+// A few long clips: the CRC slices and the TOC chunks (256 frames each) are one launch - blockIdx.y below `parts` takes a
+// slice, the rows behind a chunk of the TOC (neither needs the other) - and the CRC + header follow in a launch of one
+// workgroup per clip. Two kernels one behind the other had each paid its own ramp and drain: 27.8 us for a 3-minute clip.
+__global__ __launch_bounds__(kFinThreads) void crc_and_toc_kernel(FinishArgs A) {
+    if (blockIdx.y < A.parts) crc_slice_body(A, blockIdx.x, blockIdx.y);
+    else finish_body<kFinThreads>(A, blockIdx.x, blockIdx.y - A.parts);
 }
 
 int launch_finish_files(FinishArgs A, hipStream_t s) {
@@ -361,6 +391,17 @@ int launch_finish_files(FinishArgs A, hipStream_t s) {
     memcpy(A.blk_pow, blk, sizeof blk);
     memcpy(A.byte_pow, bytep, sizeof bytep);
     memcpy(A.stripe_pow, stripep, sizeof stripep);
+    if (A.n_clips < 64 && A.max_frames && !getenv("FLO_FINISH_TWO_KERNELS")) {
+        A.toc_chunk = kFinThreads;
+        A.mode = 1;
+        const unsigned chunks = (A.max_frames + kFinThreads - 1u) / kFinThreads;
+        hipLaunchKernelGGL(crc_and_toc_kernel, dim3((unsigned)A.n_clips, A.parts + chunks), dim3(kFinThreads), 0, s, A);
+        A.mode = 2;
+        hipLaunchKernelGGL((finish_files_kernel<1024>), dim3((unsigned)A.n_clips, 1u), dim3(1024), 0, s, A);
+        hipError_t e2 = hipGetLastError();
+        return e2 == hipSuccess ? 0 : (int)e2;
+    }
+    A.mode = 0;
     hipLaunchKernelGGL(crc_slices_kernel, dim3((unsigned)A.n_clips, A.parts), dim3(kFinThreads), 0, s, A);
     if (A.n_clips < 64) {
         // a few long clips: the TOC in chunks of 1024 frames (one entry per thread)

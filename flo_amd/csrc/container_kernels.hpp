@@ -25,6 +25,7 @@ struct FinishArgs {
     unsigned int *part_reg;                 // [n_clips * parts] scratch: CRC register of every slice
     unsigned int max_frames;                // frames of the longest clip (0 = unknown: one workgroup writes a clip's whole TOC)
     unsigned int toc_chunk;                 // set by launch_finish_files: frames per TOC workgroup (0 = all)
+    unsigned int mode;                      // set by launch_finish_files: 0 TOC + CRC + header, 1 the TOC (+ total_samples) only, 2 CRC + header only
     // powers of x modulo the CRC polynomial (reflected), filled in by launch_finish_files
     unsigned int x8pow2[40];                // x^(8 * 2^j)
     unsigned int blk_pow[256];              // x^(8 * 64 * i)
