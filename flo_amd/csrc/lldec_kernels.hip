@@ -7,9 +7,10 @@
 // A Rice stream is a chain: code i + 1 starts where code i ends. What breaks the chain is that, for a fixed k, the
 // only thing a stretch of the stream needs to know about everything before it is *how it is entered*: in the middle
 // of a unary run, or with 0..k remainder bits still to skip. So
-//   1. rice_scan   : the stream is cut into tiles of 2048 bits; a lane walks one tile from one of the k + 2 possible
-//                    entry states (k + 2 lanes per tile, 64 / (k + 2) tiles per wavefront) and records where it leaves
-//                    the tile and how many codes started inside it;
+//   1. rice_scan   : the stream is cut into tiles of kRiceTileBits (1024) bits; a lane walks one tile from one of the
+//                    k + 2 possible entry states (k + 2 lanes per tile, 64 / (k + 2) tiles per wavefront; parses that have
+//                    met continue as one, see the kernel) and records where it leaves the tile and how many codes
+//                    started inside it;
 //   2. rice_chain  : one wavefront per wrapper follows those tables from tile to tile (a few hundred dependent LDS
 //                    reads) and notes, per tile, the real entry state and the index of its first code;
 //   3. rice_decode : a lane per tile walks its tile once more from the now known entry and writes the residuals;
@@ -90,18 +91,8 @@ __device__ __forceinline__ void stage_words(const uint8_t *p, uint32_t len, uint
     }
 }
 
-// the 32 bits that start at bit `pos` of a big-endian word array
-__device__ __forceinline__ uint32_t window32(const uint32_t *w, uint32_t pos) {
-    const uint32_t i = pos >> 5, sh = pos & 31u;
-    const unsigned long long two = ((unsigned long long)w[i] << 32) | w[i + 1];
-    return (uint32_t)((two << sh) >> 32);
-}
 __device__ __forceinline__ uint32_t leading_ones(uint32_t x) { return x == 0xFFFFFFFFu ? 32u : (uint32_t)__clz((int)~x); }
 
-__device__ __forceinline__ bool is_rice(const LlChannelDev &c) {
-    const bool has_coeffs = c.n_coeffs > 0, has_res = c.len > 0;
-    return has_res && (has_coeffs || c.shift_bits >= 128);
-}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ 1. tile tables
