@@ -329,6 +329,7 @@ struct flo_batch {
     uint32_t *d_frame_size = nullptr;
     uint64_t *d_clip_bytes = nullptr;
     uint32_t *d_crc = nullptr, *d_part = nullptr, *d_next = nullptr;
+    float *d_bmax = nullptr;   // band maxima of every frame (frame-parallel form: pass 1 -> pass 2)
     float *d_at = nullptr, *d_sprev = nullptr;
     uint8_t *d_slots = nullptr;
     uint64_t *d_frame_off = nullptr;
@@ -359,7 +360,7 @@ extern "C" void flo_batch_destroy(flo_batch *b) {
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
     void *ptrs[] = {b->d_pcm, b->d_plan, b->d_hops, b->d_out, b->d_frame_size, b->d_clip_bytes, b->d_crc, b->d_part, b->d_at,
-                    b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw, b->d_pack_plan, b->d_next};
+                    b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw, b->d_pack_plan, b->d_next, b->d_bmax};
     for (void *p : ptrs)
         if (p) pool_free(p);
     if (b->ev_pack_plan) hipEventDestroy(b->ev_pack_plan);
@@ -553,6 +554,7 @@ static int alloc_frame_scratch(flo_batch *b) {
     const size_t n = (size_t)b->total_frames * b->ch * 32 * sizeof(float);
     HIPCHK(c, pool_alloc(&b->d_at, n));
     HIPCHK(c, pool_alloc(&b->d_sprev, n));
+    HIPCHK(c, pool_alloc(&b->d_bmax, n));
     HIPCHK(c, pool_alloc(&b->d_slots, (size_t)b->total_frames * lossy_slot_bytes(b->ch)));
     HIPCHK(c, pool_alloc(&b->d_frame_off, (size_t)(b->total_frames + 1) * 8));
     return FLO_OK;
@@ -577,6 +579,7 @@ static LossyArgs make_args(flo_batch *b) {
     A.frame_size = b->d_frame_size;
     A.clip_bytes = (unsigned long long *)b->d_clip_bytes;
     A.a_t = b->d_at;
+    A.bmax_t = b->d_bmax;
     A.s_prev_out = b->d_sprev;
     A.s_prev = b->d_sprev;
     A.slots = b->d_slots;

@@ -1012,15 +1012,24 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
             for (int e = 0; e < 16; e++) d[e] = ch ? c[e].y : c[e].x;
         }
     }
-    float energy1, bmax1;   // channel 0's band b on lane b, channel 1's on lane 32 + b
-    band_stats_2(lane, c, lds.u.a.slot, T, energy1, bmax1);
+    // channel 0's band b on lane b, channel 1's on lane 32 + b. Pass 1 makes the band statistics and the masking level
+    // before temporal masking and leaves both for pass 2, which only transforms again (the coefficients are what it cannot
+    // keep): statistics and spreading are a sixth of a frame's instructions.
     const int bnd = lane & 31, up = lane >> 5;
-    const float rcount = T.pack[kRowLane * 64 + bnd].z;
-    const float a = spread_threshold_2(lane, energy1, rcount, T);
+    float a, bmax1;
     if (PASS == 1) {
-        if (bnd < 25) A.a_t[(gframe * 2 + up) * 32 + bnd] = a;
+        float energy1;
+        band_stats_2(lane, c, lds.u.a.slot, T, energy1, bmax1);
+        const float rcount = T.pack[kRowLane * 64 + bnd].z;
+        a = spread_threshold_2(lane, energy1, rcount, T);
+        if (bnd < 25) {
+            A.a_t[(gframe * 2 + up) * 32 + bnd] = a;
+            A.bmax_t[(gframe * 2 + up) * 32 + bnd] = bmax1;
+        }
         return;
     }
+    a = bnd < 25 ? A.a_t[(gframe * 2 + up) * 32 + bnd] : 0.f;
+    bmax1 = bnd < 25 ? A.bmax_t[(gframe * 2 + up) * 32 + bnd] : 0.f;
     const float prev = bnd < 25 ? A.s_prev[(gframe * 2 + up) * 32 + bnd] : 0.f;
     const float sl = max_raw(a, prev * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
     const float tl1 = masking_amplitude(sl, T.smr_thr);

@@ -26,6 +26,7 @@ struct LossyArgs {
     unsigned long long *clip_bytes;          // [n_clips] DATA chunk size
     // frame-parallel form
     float *a_t;                              // [total_frames][nch][32] masking level before temporal masking
+    float *bmax_t;                           // [total_frames][nch][32] band maxima (frame-parallel stereo form: pass 1 leaves them for pass 2)
     float *s_prev_out;                       // [total_frames][nch][32] scan output
     const float *s_prev;                     // same buffer, read by pass 2
     uint8_t *slots;                          // [total_frames][slot_bytes]
