@@ -330,6 +330,7 @@ struct flo_batch {
     uint64_t *d_clip_bytes = nullptr;
     uint32_t *d_crc = nullptr, *d_part = nullptr, *d_next = nullptr;
     float *d_bmax = nullptr;   // band maxima of every frame (frame-parallel form: pass 1 -> pass 2)
+    void *d_coef = nullptr;    // ... and, for a few long stereo clips, every frame's coefficients (8 KB per frame)
     float *d_at = nullptr, *d_sprev = nullptr;
     uint8_t *d_slots = nullptr;
     uint64_t *d_frame_off = nullptr;
@@ -360,7 +361,7 @@ extern "C" void flo_batch_destroy(flo_batch *b) {
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
     void *ptrs[] = {b->d_pcm, b->d_plan, b->d_hops, b->d_out, b->d_frame_size, b->d_clip_bytes, b->d_crc, b->d_part, b->d_at,
-                    b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw, b->d_pack_plan, b->d_next, b->d_bmax};
+                    b->d_sprev, b->d_slots, b->d_frame_off, b->d_dbg_coeffs, b->d_dbg_q, b->d_dbg_sfw, b->d_pack_plan, b->d_next, b->d_bmax, b->d_coef};
     for (void *p : ptrs)
         if (p) pool_free(p);
     if (b->ev_pack_plan) hipEventDestroy(b->ev_pack_plan);
@@ -555,6 +556,9 @@ static int alloc_frame_scratch(flo_batch *b) {
     HIPCHK(c, pool_alloc(&b->d_at, n));
     HIPCHK(c, pool_alloc(&b->d_sprev, n));
     HIPCHK(c, pool_alloc(&b->d_bmax, n));
+    // one 3-minute clip: 63 MB that never leave the memory-side cache; a batch of thousands of clips forced into this form
+    // transforms twice instead
+    if (b->ch == 2 && (size_t)b->total_frames * 8192 <= ((size_t)256 << 20) && !getenv("FLO_NO_COEF_HANDOVER")) HIPCHK(c, pool_alloc(&b->d_coef, (size_t)b->total_frames * 8192));
     HIPCHK(c, pool_alloc(&b->d_slots, (size_t)b->total_frames * lossy_slot_bytes(b->ch)));
     HIPCHK(c, pool_alloc(&b->d_frame_off, (size_t)(b->total_frames + 1) * 8));
     return FLO_OK;
@@ -580,6 +584,7 @@ static LossyArgs make_args(flo_batch *b) {
     A.clip_bytes = (unsigned long long *)b->d_clip_bytes;
     A.a_t = b->d_at;
     A.bmax_t = b->d_bmax;
+    A.coef_t = (float4 *)b->d_coef;
     A.s_prev_out = b->d_sprev;
     A.s_prev = b->d_sprev;
     A.slots = b->d_slots;

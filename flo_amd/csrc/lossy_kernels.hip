@@ -990,7 +990,15 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
     const LossyDevTables &T = A.T;   // constant rows straight from global memory: one frame per wave reads each once
 
     v2f c[16];
-    {
+    if (PASS == 2 && A.coef_t) {   // (uniform) pass 1 left this frame's coefficients as its lanes held them
+        const float4 *src = A.coef_t + gframe * 512ull + (unsigned)lane;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float4 v = src[64 * k];
+            c[2 * k] = (v2f){v.x, v.y};
+            c[2 * k + 1] = (v2f){v.z, v.w};
+        }
+    } else {
         v2f ae[8], ao[8], be[8], bo[8];
         if (h == 0) {   // pre-roll: 1024 zeros (encoder.rs:177)
 #pragma unroll
@@ -1003,6 +1011,11 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
         fold_2(lane, ae, ao, be, bo, zr, zi, T);
         fft512_2(lane, zr, zi, lds.u.xch4, T);
         post_rotate_transpose_2(lane, zr, zi, lds.u.coef2, c, T);
+        if (PASS == 1 && A.coef_t) {
+            float4 *dst = A.coef_t + gframe * 512ull + (unsigned)lane;
+#pragma unroll
+            for (int k = 0; k < 8; k++) dst[64 * k] = make_float4(c[2 * k].x, c[2 * k].y, c[2 * k + 1].x, c[2 * k + 1].y);
+        }
     }
     if (PASS == 2 && A.dbg_coeffs) {
 #pragma unroll

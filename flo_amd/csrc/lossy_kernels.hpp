@@ -27,6 +27,8 @@ struct LossyArgs {
     // frame-parallel form
     float *a_t;                              // [total_frames][nch][32] masking level before temporal masking
     float *bmax_t;                           // [total_frames][nch][32] band maxima (frame-parallel stereo form: pass 1 leaves them for pass 2)
+    float4 *coef_t;                          // nullable [total_frames][8][64]: the stereo coefficients as pass 1's lanes hold them (few frames only:
+                                             // 8 KB per frame; pass 2 reads them back instead of transforming again)
     float *s_prev_out;                       // [total_frames][nch][32] scan output
     const float *s_prev;                     // same buffer, read by pass 2
     uint8_t *slots;                          // [total_frames][slot_bytes]
