@@ -1200,11 +1200,12 @@ __device__ __forceinline__ void quant_rows_load(const int lane, const LossyDevTa
         R.bo4[g] = T.pack[(kRowBo + g) * 64 + lane];
     }
 }
-__device__ __forceinline__ void quantise_2(const int lane, const v2f (&c)[16], const StereoLds &L, const LossyDevTables &T,
+// (ts: the per-band table in LDS - amplitude thresholds (left, right), scale factors (left, right))
+__device__ __forceinline__ void quantise_2(const int lane, const v2f (&c)[16], const float4 *ts, const LossyDevTables &T,
                                            const QuantRows &R, uint32_t (&xs)[2][8]) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) v4f lds_f4;
-    const uint32_t ts0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)L.u.a.ts);
+    const uint32_t ts0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)ts);
     const uint32_t sgn_mask = 0x7FFFFFFFu;
     uint32_t phalf = 0x3EFFFFFFu;
     asm volatile("" : "+v"(phalf));   // kept in a register: a VOP3 operand cannot be a literal

@@ -19,6 +19,7 @@
 
 #include <mutex>
 #include <set>
+#include <type_traits>
 #include <utility>
 
 #include "lossy_device.hpp"
@@ -967,14 +968,30 @@ __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
 // Stereo frames, shipped quantiser, PCM input: the frame-parallel passes built from the lock-step stereo device
 // functions of lossy_chain2q_kernel (packed f32 transform of both channels, both channels' masking in one pass, ballot
 // packer) - one wave does a frame's transform AND packing here. Same bytes as every other form (tests compare them).
-template <int PASS>
+// FROMCOEF (pass 2 only): the coefficients come from pass 1's hand-over buffer (A.coef_t). That pass needs no FFT exchange
+// buffer: 9.7 KB of LDS instead of 14.4 and 128 registers - sixteen frames per CU instead of eleven, two rounds of
+// workgroups for a 3-minute clip instead of three.
+struct QuantOnlyLds {
+    float4 ts[32];
+    uint32_t qh[2][512];
+};
+template <int PASS, bool FROMCOEF = false>
 __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
-    __shared__ StereoLds lds;
+    constexpr bool kSmall = PASS == 2 && FROMCOEF;
+    __shared__ typename std::conditional<kSmall, QuantOnlyLds, StereoLds>::type lds;
     __shared__ __attribute__((aligned(16))) uint8_t stage[PASS == 2 ? kFrameCap + 64 + 256 : 16];
     // the re-dealing buffer of the integers lies over the analysis buffers, which are dead once the quantiser has read the
     // band table (a wave's LDS instructions execute in order): 14.4 KB per frame instead of 18.5, eleven frames per CU
     static_assert(sizeof(StereoLds) >= 2 * 512 * 4, "the integers of both channels fit the analysis buffers");
-    uint32_t (*qh)[512] = reinterpret_cast<uint32_t (*)[512]>(&lds);
+    uint32_t (*qh)[512];
+    float4 *ts_tab;
+    if constexpr (kSmall) {
+        qh = lds.qh;
+        ts_tab = lds.ts;
+    } else {
+        qh = reinterpret_cast<uint32_t (*)[512]>(&lds);
+        ts_tab = lds.u.a.ts;
+    }
     __shared__ uint32_t runtab[PASS == 2 ? kRunTabEntries : 1];
     const int lane = lane_id();
     const unsigned long long gframe = blockIdx.x;
@@ -990,7 +1007,7 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
     const LossyDevTables &T = A.T;   // constant rows straight from global memory: one frame per wave reads each once
 
     v2f c[16];
-    if (PASS == 2 && A.coef_t) {   // (uniform) pass 1 left this frame's coefficients as its lanes held them
+    if constexpr (kSmall) {   // pass 1 left this frame's coefficients as its lanes held them
         const float4 *src = A.coef_t + gframe * 512ull + (unsigned)lane;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -1030,7 +1047,7 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
     // keep): statistics and spreading are a sixth of a frame's instructions.
     const int bnd = lane & 31, up = lane >> 5;
     float a, bmax1;
-    if (PASS == 1) {
+    if constexpr (PASS == 1) {
         float energy1;
         band_stats_2(lane, c, lds.u.a.slot, T, energy1, bmax1);
         const float rcount = T.pack[kRowLane * 64 + bnd].z;
@@ -1050,15 +1067,15 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
     const float sfv1 = bm > 1e-10f ? __fdiv_rn(30000.0f, bm) : 1.0f;   // encoder.rs:121-127
     const uint32_t sfw1 = sf_word(sfv1);
     if (bnd < 25) {
-        reinterpret_cast<float *>(&lds.u.a.ts[bnd])[up] = tl1;
-        reinterpret_cast<float *>(&lds.u.a.ts[bnd])[2 + up] = sfv1;
+        reinterpret_cast<float *>(&ts_tab[bnd])[up] = tl1;
+        reinterpret_cast<float *>(&ts_tab[bnd])[2 + up] = sfv1;
     }
     wave_sync();
     uint32_t xs[2][8];
     {
         QuantRows qrows;
         quant_rows_load(lane, T, qrows);
-        quantise_2(lane, c, lds, T, qrows, xs);
+        quantise_2(lane, c, ts_tab, T, qrows, xs);
     }
     if (A.dbg_q) {
 #pragma unroll
@@ -1643,6 +1660,7 @@ int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s) {
         else hipLaunchKernelGGL((lossy_frame_kernel<1, 2, false>), g, b, 0, s, A);
     } else if (A.nch == 2 && !A.exact && !A.in_coeffs && !getenv("FLO_FRAME_OLD")) {
         if (pass == 1) hipLaunchKernelGGL((lossy_frame2x_kernel<1>), g, b, 0, s, A);
+        else if (A.coef_t) hipLaunchKernelGGL((lossy_frame2x_kernel<2, true>), g, b, 0, s, A);
         else hipLaunchKernelGGL((lossy_frame2x_kernel<2>), g, b, 0, s, A);
     } else if (A.nch == 2) {
         if (pass == 1) hipLaunchKernelGGL((lossy_frame_kernel<2, 1, false>), g, b, 0, s, A);
