@@ -968,6 +968,7 @@ __global__ __launch_bounds__(64) void lossy_frame_kernel(LossyArgs A) {
 // Stereo frames, shipped quantiser, PCM input: the frame-parallel passes built from the lock-step stereo device
 // functions of lossy_chain2q_kernel (packed f32 transform of both channels, both channels' masking in one pass, ballot
 // packer) - one wave does a frame's transform AND packing here. Same bytes as every other form (tests compare them).
+constexpr int kScanBlock = 64;   // frames of history the temporal chain is warmed up over (lossy_scan_kernel, and pass 2 below)
 // FROMCOEF (pass 2 only): the coefficients come from pass 1's hand-over buffer (A.coef_t). That pass needs no FFT exchange
 // buffer: 9.7 KB of LDS instead of 14.4 and 128 registers - sixteen frames per CU instead of eleven, two rounds of
 // workgroups for a 3-minute clip instead of three.
@@ -1060,7 +1061,34 @@ __global__ __launch_bounds__(64) void lossy_frame2x_kernel(LossyArgs A) {
     }
     a = bnd < 25 ? A.a_t[(gframe * 2 + up) * 32 + bnd] : 0.f;
     bmax1 = bnd < 25 ? A.bmax_t[(gframe * 2 + up) * 32 + bnd] : 0.f;
-    const float prev = bnd < 25 ? A.s_prev[(gframe * 2 + up) * 32 + bnd] : 0.f;
+    float prev = 0.f;
+    if constexpr (kSmall) {
+        // The temporal chain s_t = max(a_t, 0.7 s_(t-1)) over the 64 frames before this one, from 0: what lossy_scan_kernel
+        // computes for the first frame of each of its blocks (history older than 64 frames cannot reach a threshold, see
+        // there), here for every frame by the workgroup that needs it - 64 independent 4-byte loads per lane and a chain
+        // of 128 instructions instead of a launch of its own (10.6 us for a 3-minute clip) between the passes.
+        const float *at = A.a_t + ((gframe - h) * 2 + (unsigned)up) * 32 + (unsigned)(bnd < 25 ? bnd : 0);
+        float s = 0.f;
+        if (h >= (unsigned)kScanBlock) {   // (uniform)
+            float av[kScanBlock];
+#pragma unroll
+            for (int j = 0; j < kScanBlock; j++) av[j] = at[(unsigned long long)(h - kScanBlock + j) * 64];
+#pragma unroll
+            for (int j = 0; j < kScanBlock; j++) s = fmaxf(av[j], s * 0.7f);
+        } else {
+            for (unsigned hb = 0; hb < h; hb += 16) {
+                float av[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) av[j] = hb + j < h ? at[(unsigned long long)(hb + j) * 64] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    if (hb + j < h) s = fmaxf(av[j], s * 0.7f);
+            }
+        }
+        prev = s;
+    } else {
+        prev = bnd < 25 ? A.s_prev[(gframe * 2 + up) * 32 + bnd] : 0.f;
+    }
     const float sl = max_raw(a, prev * 0.7f);   // temporal masking (psychoacoustic.rs:196-203)
     const float tl1 = masking_amplitude(sl, T.smr_thr);
     const float bm = bmax1;
@@ -1234,7 +1262,6 @@ __global__ __launch_bounds__(64) void lossy_frame_n_kernel(LossyArgs A) {
 // ulp of 10) vanish in fl(s - 10) and in max(s, ath) - 10, so every threshold derived from the blocked scan is
 // bit-identical to the sequential chain's (the chain kernel keeps the true sequential state).
 // Writes the state seen BEFORE each frame.
-constexpr int kScanBlock = 64;
 __global__ void lossy_scan_kernel(LossyArgs A) {
     const unsigned clip = blockIdx.x;   // clips in x: gridDim.y stops at 65535
     if (clip >= (unsigned)A.n_clips) return;
@@ -1675,7 +1702,10 @@ int launch_lossy_frames_pass(const LossyArgs &A, int pass, hipStream_t s) {
     FLO_LAUNCH_CHECK();
     return 0;
 }
+// the stereo frame-parallel form with handed-over coefficients walks the temporal chain inside pass 2: no scan launch
+bool lossy_pass2_scans_itself(const LossyArgs &A) { return A.nch == 2 && !A.exact && !A.in_coeffs && A.coef_t && !getenv("FLO_FRAME_OLD"); }
 int launch_lossy_scan(const LossyArgs &A, hipStream_t s) {
+    if (lossy_pass2_scans_itself(A)) return 0;
     unsigned max_hops = (unsigned)A.max_hops;
     hipLaunchKernelGGL(lossy_scan_kernel, dim3(A.n_clips, (max_hops + kScanBlock - 1) / kScanBlock), dim3(32 * A.nch), 0, s, A);
     FLO_LAUNCH_CHECK();
