@@ -196,7 +196,7 @@ class Context:
     def analyze(self, samples, sample_rate, channels, peaks_per_second=50):
         """waveform peaks, spectral fingerprint and EBU R128 integrated loudness, computed on the device"""
         p = _f32(samples)
-        peaks = np.zeros(p.size // max(channels, 1) + 16, np.float32)
+        peaks = np.zeros(int(np.ceil(p.size // max(channels, 1) * peaks_per_second / max(sample_rate, 1))) + 16, np.float32)
         a = _native.Analysis()
         self._chk(self._L.flo_analyze(self._h, p.ctypes.data, p.size, sample_rate, channels, peaks_per_second,
                                       peaks.ctypes.data, peaks.size, C.byref(a)))

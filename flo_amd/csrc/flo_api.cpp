@@ -2563,7 +2563,14 @@ static int analyze_impl(flo_ctx *c, const float *pcm, const float *pcm_dev, size
     if (!pcm_dev) {
         std::vector<UploadSeg> segs{{d_pcm.p, pcm, n * 4}};
         std::string err;
+        const auto tu0 = std::chrono::steady_clock::now();
         if (stager_upload(c->stager, segs, c->stream, err) != 0) return fail(c, FLO_ERR_DEVICE, err);
+        if (getenv("FLO_TRACE")) {
+            hipStreamSynchronize(c->stream);
+            fprintf(stderr, "[flo] analysis: upload of %.1f MB took %.0f us (%s)\n", (double)n * 4 / 1e6,
+                    (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tu0).count() / 1e3,
+                    stager_upload_choice(c->stager, nullptr, nullptr));
+        }
     }
     HIPCHK(c, hipMemsetAsync(d_res.p, 0, o_kst, c->stream));   // (what lies behind is fully written by its kernels)
     HIPCHK(c, hipMemcpyAsync((char *)d_res.p + o_tw, tw, sizeof tw, hipMemcpyHostToDevice, c->stream));
@@ -2734,7 +2741,9 @@ static int analysis_metadata_impl(flo_ctx *c, const float *pcm, const float *pcm
     *out = nullptr;
     *out_len = 0;
     if (!ch || !sr || !pps) return fail(c, FLO_ERR_ARG, "flo_analysis_metadata: bad argument");
-    std::vector<float> peaks(n / ch + 16);
+    // (one peak per 1 / pps seconds: ceil(frames * pps / rate) of them - a vector of one float per sample frame was 32 MB of
+    // zeroed fresh pages for a 3-minute clip, 4 ms of a 7 ms call)
+    std::vector<float> peaks((size_t)std::ceil((double)(n / ch) * (double)pps / (double)sr) + 16);
     flo_analysis an;
     int rc = analyze_impl(c, pcm, pcm_dev, n, sr, ch, pps, peaks.data(), peaks.size(), &an);
     if (rc != FLO_OK) return rc;
